@@ -1,0 +1,271 @@
+"""CPU oracle for the caf_rust filterbank CAF hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The shipped product (caf_cookoff_amd/) never does.
+
+Two independent restatements of the reference algorithm live here:
+
+* ``np_*``  -- numpy (pocketfft) restatement, used to generate tests/golden/.
+* ``COracle`` -- ctypes binding of oracle/caf_oracle.c (own FFT), used as the
+  timed CPU baseline and as a second opinion.
+
+Parity pin: the ten (freq, samp_idx) known answers of
+caf_rust/tests/test.rs:14-316 on tests/golden/data (see tests/test_oracle_kats.py).
+Surface VALUES are not pinned by any test of the reference; the
+two restatements are cross-checked against each other instead.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+
+
+# --------------------------------------------------------------------------
+# shift lists
+# --------------------------------------------------------------------------
+def gen_float_shifts(start: float, end: float, step: float) -> np.ndarray:
+    """caf_rust/tests/test.rs:335-352 -- integer milli-Hz range, end-exclusive."""
+    s = int(start * 1000.0)  # `as i32` truncates toward zero, like int()
+    e = int(end * 1000.0)
+    st = int(step * 1000.0)
+    return np.array([m / 1e3 for m in range(s, e, st)], dtype=np.float64)
+
+
+def bench_shifts() -> np.ndarray:
+    """caf_rust/benches/caf_bench.rs:31-35 and main.rs:18-22 -- 400 shifts."""
+    return np.array([m / 1e3 for m in range(-100000, 100000, 500)], dtype=np.float64)
+
+
+# --------------------------------------------------------------------------
+# file format
+# --------------------------------------------------------------------------
+def read_file_c64(path) -> np.ndarray:
+    """caf_rust/src/utils.rs:10-35 -- LE f32 I/Q pairs widened to Complex64."""
+    return np.fromfile(path, dtype="<c8").astype(np.complex128)
+
+
+def load_pair(data_dir, needle_name: str, haystack_name: str):
+    """tests/test.rs:319-331 (load_files): haystack.resize(needle.len())."""
+    needle = read_file_c64(Path(data_dir) / needle_name)
+    hay = read_file_c64(Path(data_dir) / haystack_name)
+    n = len(needle)
+    if len(hay) >= n:
+        hay = hay[:n].copy()
+    else:
+        hay = np.concatenate([hay, np.zeros(n - len(hay), dtype=np.complex128)])
+    return needle, hay
+
+
+# --------------------------------------------------------------------------
+# numpy restatement
+# --------------------------------------------------------------------------
+def np_phase_step(freq_shift: float, fs: int) -> float:
+    """mod.rs:54-56: dt = 1.0/(fs as f64); 2.0*PI*freq_shift*dt, left to right."""
+    dt = 1.0 / float(fs)
+    return ((2.0 * math.pi) * float(freq_shift)) * dt
+
+
+def np_apply_freq_shift(samples: np.ndarray, freq_shift: float, fs: int) -> np.ndarray:
+    """mod.rs:46-65 -- phasor recurrence (samp *= accum; accum *= shift)."""
+    ph = np_phase_step(freq_shift, fs)
+    shift = complex(math.cos(ph), math.sin(ph))
+    out = np.empty(len(samples), dtype=np.complex128)
+    acc = complex(1.0, 0.0)
+    for i, x in enumerate(samples):
+        out[i] = complex(x) * acc
+        acc = acc * shift
+    return out
+
+
+def np_apply_freq_shift_fast(samples: np.ndarray, freq_shift: float, fs: int) -> np.ndarray:
+    """Same recurrence via cumprod (numpy's complex product == the scalar one)."""
+    ph = np_phase_step(freq_shift, fs)
+    shift = complex(math.cos(ph), math.sin(ph))
+    fac = np.full(len(samples), shift, dtype=np.complex128)
+    if len(fac):
+        fac[0] = 1.0
+    return np.asarray(samples, dtype=np.complex128) * np.cumprod(fac)
+
+
+def np_xcor(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """xcor_rustfft.rs:51-78: IFFT_unnorm( FFT(a)*conj(FFT(b)) / n )."""
+    n = len(a)
+    assert len(b) == n
+    A = np.fft.fft(a)
+    B = np.conj(np.fft.fft(b))
+    return np.fft.ifft((A * B) / n) * n  # numpy's ifft carries 1/n; undo it
+
+
+def np_caf_surface(needle, haystack, freqs_hz, fs, want_surface=True):
+    """mod.rs:121-166.  Returns (surface[F,2N] or None, row_idx[F], row_val[F])."""
+    needle = np.asarray(needle, dtype=np.complex128)
+    haystack = np.asarray(haystack, dtype=np.complex128)
+    n = len(needle)
+    assert len(haystack) == n  # xcor_rustfft.rs:54-55 would panic otherwise
+    L = 2 * n
+    a = np.concatenate([needle, np.zeros(n, dtype=np.complex128)])
+    h = np.concatenate([haystack, np.zeros(n, dtype=np.complex128)])
+    H = np.fft.fft(h)
+    F = len(freqs_hz)
+    surf = np.empty((F, L), dtype=np.float64) if want_surface else None
+    ridx = np.zeros(F, dtype=np.uint64)
+    rval = np.zeros(F, dtype=np.float64)
+    for r, f in enumerate(freqs_hz):
+        s = np_apply_freq_shift_fast(a, f, fs)
+        C = (H * np.conj(np.fft.fft(s))) / L
+        c = np.fft.ifft(C) * L
+        mag = c.real * c.real + c.imag * c.imag
+        k = int(np.argmax(mag)) if L else 0  # first max == first strictly-greater
+        if L and mag[k] > 0.0:
+            ridx[r], rval[r] = k, mag[k]
+        if want_surface:
+            surf[r] = mag
+    return surf, ridx, rval
+
+
+def np_find_peak(freqs_hz, row_idx, row_val):
+    """mod.rs:31-42."""
+    bf, bi, bv = 0.0, 0, 0.0
+    for f, i, v in zip(freqs_hz, row_idx, row_val):
+        if v > bv:
+            bf, bi, bv = float(f), int(i), float(v)
+    return bf, bi
+
+
+# --------------------------------------------------------------------------
+# C restatement (ctypes)
+# --------------------------------------------------------------------------
+def build_c_oracle(force: bool = False) -> Path:
+    so = _HERE / "libcaf_oracle.so"
+    src = _HERE / "caf_oracle.c"
+    if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "-s"], check=True)
+    return so
+
+
+class COracle:
+    """ctypes view of oracle/caf_oracle.c."""
+
+    def __init__(self):
+        so = build_c_oracle()
+        L = ctypes.CDLL(str(so))
+        dp = ctypes.POINTER(ctypes.c_double)
+        up = ctypes.POINTER(ctypes.c_uint64)
+        L.oracle_apply_freq_shift.argtypes = [dp, ctypes.c_size_t, ctypes.c_double, ctypes.c_uint32, dp]
+        L.oracle_apply_freq_shift.restype = None
+        L.oracle_fft.argtypes = [dp, dp, ctypes.c_size_t, ctypes.c_int]
+        L.oracle_fft.restype = ctypes.c_int
+        L.oracle_xcor_new.argtypes = [ctypes.c_size_t]
+        L.oracle_xcor_new.restype = ctypes.c_void_p
+        L.oracle_xcor_free.argtypes = [ctypes.c_void_p]
+        L.oracle_xcor_run.argtypes = [ctypes.c_void_p, dp, dp, dp]
+        L.oracle_xcor_run.restype = ctypes.c_int
+        L.oracle_caf_surface_threads.argtypes = [dp, dp, ctypes.c_size_t, dp, ctypes.c_size_t,
+                                                 ctypes.c_uint32, dp, up, dp, ctypes.c_int, ctypes.c_int]
+        L.oracle_caf_surface_threads.restype = ctypes.c_int
+        L.oracle_find_peak.argtypes = [dp, up, dp, ctypes.c_size_t, dp, up]
+        L.oracle_find_peak.restype = None
+        L.oracle_gen_float_shifts.argtypes = [ctypes.c_double] * 3 + [dp, ctypes.c_size_t]
+        L.oracle_gen_float_shifts.restype = ctypes.c_size_t
+        self.L = L
+
+    @staticmethod
+    def _c(a):
+        a = np.ascontiguousarray(a, dtype=np.complex128)
+        return a, a.view(np.float64).ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+    @staticmethod
+    def _d(a):
+        return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+    def apply_freq_shift(self, samples, freq_shift, fs):
+        s, sp = self._c(samples)
+        out = np.empty(len(s), dtype=np.complex128)
+        self.L.oracle_apply_freq_shift(sp, len(s), float(freq_shift), int(fs),
+                                       self._d(out.view(np.float64)))
+        return out
+
+    def fft(self, x, inverse=False):
+        s, sp = self._c(x)
+        out = np.empty(len(s), dtype=np.complex128)
+        rc = self.L.oracle_fft(sp, self._d(out.view(np.float64)), len(s), int(bool(inverse)))
+        if rc:
+            raise ValueError(f"oracle_fft rc={rc}")
+        return out
+
+    def xcor(self, a, b):
+        a, ap = self._c(a)
+        b, bp = self._c(b)
+        if len(a) != len(b):
+            raise AssertionError("a.len() == self.n")  # xcor_rustfft.rs:54-55
+        h = self.L.oracle_xcor_new(len(a))
+        if not h:
+            raise ValueError("n must be a power of two")
+        try:
+            out = np.empty(len(a), dtype=np.complex128)
+            self.L.oracle_xcor_run(h, ap, bp, self._d(out.view(np.float64)))
+        finally:
+            self.L.oracle_xcor_free(h)
+        return out
+
+    def caf_surface(self, needle, haystack, freqs_hz, fs, want_surface=True,
+                    hoist=False, nthreads=1):
+        nd, npn = self._c(needle)
+        hs, hp = self._c(haystack)
+        assert len(nd) == len(hs)
+        fr = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        F, n = len(fr), len(nd)
+        surf = np.empty((F, 2 * n), dtype=np.float64) if want_surface else None
+        ridx = np.zeros(F, dtype=np.uint64)
+        rval = np.zeros(F, dtype=np.float64)
+        rc = self.L.oracle_caf_surface_threads(
+            npn, hp, n, self._d(fr), F, int(fs),
+            self._d(surf) if want_surface else None,
+            ridx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), self._d(rval),
+            int(bool(hoist)), int(nthreads))
+        if rc:
+            raise ValueError(f"oracle_caf_surface rc={rc}")
+        return surf, ridx, rval
+
+    def find_peak(self, freqs_hz, row_idx, row_val):
+        fr = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        ri = np.ascontiguousarray(row_idx, dtype=np.uint64)
+        rv = np.ascontiguousarray(row_val, dtype=np.float64)
+        bf = ctypes.c_double()
+        bi = ctypes.c_uint64()
+        self.L.oracle_find_peak(self._d(fr), ri.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                self._d(rv), len(fr), ctypes.byref(bf), ctypes.byref(bi))
+        return bf.value, int(bi.value)
+
+    def gen_float_shifts(self, start, end, step):
+        n = self.L.oracle_gen_float_shifts(start, end, step, None, 0)
+        out = np.empty(n, dtype=np.float64)
+        self.L.oracle_gen_float_shifts(start, end, step, self._d(out), n)
+        return out
+
+
+# the reference's ten known answers: caf_rust/tests/test.rs (line numbers in SURVEY.md section 4)
+KATS = [
+    # k, haystack file, (start, end, step), expected (freq, idx)
+    (0, "chirp_0_T+202samp_F+69.25Hz.c64", (-100.0, 100.0, 0.25), (69.25, 202)),
+    (1, "chirp_1_T+78samp_F+35.99Hz.c64", (-50.0, 50.0, 1.0), (36.0, 78)),
+    (2, "chirp_2_T+169samp_F+32.16Hz.c64", (30.0, 35.0, 0.05), (32.15, 169)),
+    (3, "chirp_3_T+151samp_F-76.22Hz.c64", (-100.0, 100.0, 0.25), (-76.25, 151)),
+    (4, "chirp_4_T+70samp_F+82.89Hz.c64", (80.0, 100.0, 0.1), (82.9, 70)),
+    (5, "chirp_5_T+177samp_F-92.72Hz.c64", (-100.0, 100.0, 0.25), (-92.75, 177)),
+    (6, "chirp_6_T+15samp_F-49.69Hz.c64", (-100.0, 100.0, 0.25), (-49.75, 15)),
+    (7, "chirp_7_T+84samp_F+68.26Hz.c64", (-100.0, 100.0, 0.25), (68.25, 84)),
+    (8, "chirp_8_T+80samp_F-46.28Hz.c64", (-100.0, 100.0, 0.25), (-46.25, 80)),
+    (9, "chirp_9_T+176samp_F+61.49Hz.c64", (-100.0, 100.0, 0.5), (61.5, 176)),
+]
+
+
+def default_data_dir() -> Path:
+    return _HERE.parent / "tests" / "golden" / "data"
