@@ -1,0 +1,100 @@
+"""ctypes loader for libcaf_hip.so (the C ABI of include/caf_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C caf_cookoff_amd/csrc``.  There is no fallback: a missing library or a
+missing GPU raises, it never silently computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libcaf_hip.so"
+
+CAF_OK = 0
+CAF_ERR_BAD_ARG = 1
+CAF_ERR_LENGTH = 2
+CAF_ERR_HIP = 3
+CAF_ERR_NOMEM = 4
+CAF_ERR_NO_DEVICE = 5
+CAF_ERR_STATE = 6
+
+CAF_C128 = 0
+CAF_C64 = 1
+
+
+class CafPeak(ctypes.Structure):
+    """``caf_peak`` of include/caf_hip.h (mod.rs:31-42 result + value/row)."""
+    _fields_ = [("val", ctypes.c_double), ("freq", ctypes.c_double),
+                ("idx", ctypes.c_uint64), ("row", ctypes.c_int64)]
+
+
+class CafError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"caf_hip error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/caf_hip.h declares: (name, restype, argtypes)
+_vp = ctypes.c_void_p
+_dp = ctypes.POINTER(ctypes.c_double)
+_fp = ctypes.POINTER(ctypes.c_float)
+_up = ctypes.POINTER(ctypes.c_uint64)
+_pp = ctypes.POINTER(CafPeak)
+_sz = ctypes.c_size_t
+_u32 = ctypes.c_uint32
+_int = ctypes.c_int
+SYMBOLS = [
+    ("caf_abi_version", _int, []),
+    ("caf_last_error_string", ctypes.c_char_p, []),
+    ("caf_device_count", _int, []),
+    ("caf_ctx_create", _int, [_int, ctypes.POINTER(_vp)]),
+    ("caf_ctx_destroy", _int, [_vp]),
+    ("caf_ctx_set_stream", _int, [_vp, _vp]),
+    ("caf_ctx_synchronize", _int, [_vp]),
+    ("caf_ctx_device_info", _int, [_vp, ctypes.POINTER(_int), ctypes.c_char_p, _sz]),
+    ("caf_apply_freq_shift_c128", _int, [_vp, _dp, _sz, ctypes.c_double, _u32, _dp]),
+    ("caf_apply_freq_shift_c64", _int, [_vp, _fp, _sz, ctypes.c_double, _u32, _fp]),
+    ("caf_xcor_c128", _int, [_vp, _dp, _dp, _sz, _dp]),
+    ("caf_xcor_c64", _int, [_vp, _fp, _fp, _sz, _fp]),
+    ("caf_surface_c128", _int, [_vp, _dp, _dp, _sz, _dp, _sz, _u32, _dp, _up, _dp, _pp]),
+    ("caf_surface_c64", _int, [_vp, _fp, _fp, _sz, _dp, _sz, _u32, _fp, _up, _fp, _pp]),
+    ("caf_find_peak", _int, [_vp, _dp, _up, _dp, _sz, _pp]),
+    ("caf_plan_create", _int, [_vp, _sz, _dp, _sz, _u32, _int, _sz, _sz, ctypes.POINTER(_vp)]),
+    ("caf_plan_destroy", _int, [_vp]),
+    ("caf_plan_path", ctypes.c_char_p, [_vp]),
+    ("caf_plan_rows", _sz, [_vp]),
+    ("caf_surface_dev", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    ("caf_plan_timing_begin", _int, [_vp]),
+    ("caf_plan_timing_end", _int, [_vp, _dp, _up]),
+]
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libcaf_hip.so and bind every declared symbol; raise if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("CAF_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise ImportError(
+            f"{path} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C caf_cookoff_amd/csrc). "
+            "caf_cookoff_amd has no CPU fallback.")
+    lib = ctypes.CDLL(str(path))
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != CAF_OK:
+        msg = load().caf_last_error_string()
+        raise CafError(rc, msg.decode() if msg else "")

@@ -1,0 +1,268 @@
+"""Host-side mirror of the reference's operator surface over the C ABI.
+
+Reference interface (caf_rust/src/caf/mod.rs:17-66): a trait ``CafSurface`` with
+associated functions ``caf_surface``, ``find_peak``, ``apply_freq_shift`` and the
+row record ``CafSurfaceRow``; plus ``xcor_rustfft::Xcor::{new, run, clone}``
+(xcor_rustfft.rs:14-93).  ``CafHip`` is the backend an eighth
+``impl CafSurface for CafHip`` would be; everything here is marshalling -- the
+arithmetic runs in the HIP kernels behind ``libcaf_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import CAF_C64, CAF_C128, CafError, CafPeak, check
+
+
+def _as_c128(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+def _as_c64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _uptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+@dataclass
+class CafSurfaceRow:
+    """mod.rs:17-22."""
+    freq: float
+    xcor_mag: Optional[np.ndarray]  # |.|^2 over 2n lags (None if the surface was not requested)
+    xcor_peak_idx: int
+    xcor_peak_val: float
+
+
+class Engine:
+    """One ``caf_ctx``: a GPU, a stream, cached plans.  Not thread-safe."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self.lib.caf_ctx_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.caf_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing ---------------------------------------------------------------
+    def set_stream(self, hip_stream: Optional[int]):
+        check(self.lib.caf_ctx_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        check(self.lib.caf_ctx_synchronize(self._h))
+
+    def device_info(self) -> Tuple[int, str]:
+        cu = ctypes.c_int()
+        buf = ctypes.create_string_buffer(128)
+        check(self.lib.caf_ctx_device_info(self._h, ctypes.byref(cu), buf, 128))
+        return cu.value, buf.value.decode()
+
+    # -- a1 -----------------------------------------------------------------------
+    def apply_freq_shift(self, samples, freq_shift: float, fs: int) -> np.ndarray:
+        """mod.rs:46-65."""
+        if np.asarray(samples).dtype == np.complex64:
+            s = _as_c64(samples)
+            out = np.empty_like(s)
+            check(self.lib.caf_apply_freq_shift_c64(self._h, _fptr(s.view(np.float32)), len(s),
+                                                    float(freq_shift), int(fs), _fptr(out.view(np.float32))))
+            return out
+        s = _as_c128(samples)
+        out = np.empty_like(s)
+        check(self.lib.caf_apply_freq_shift_c128(self._h, _dptr(s.view(np.float64)), len(s),
+                                                 float(freq_shift), int(fs), _dptr(out.view(np.float64))))
+        return out
+
+    # -- a3 -----------------------------------------------------------------------
+    def xcor(self, a, b) -> np.ndarray:
+        """xcor_rustfft.rs:51-78.  Length mismatch asserts like :54-55."""
+        if len(a) != len(b):
+            raise AssertionError("assertion failed: b.len() == self.n")
+        if np.asarray(a).dtype == np.complex64 and np.asarray(b).dtype == np.complex64:
+            a, b = _as_c64(a), _as_c64(b)
+            out = np.empty_like(a)
+            check(self.lib.caf_xcor_c64(self._h, _fptr(a.view(np.float32)), _fptr(b.view(np.float32)), len(a),
+                                        _fptr(out.view(np.float32))))
+            return out
+        a, b = _as_c128(a), _as_c128(b)
+        out = np.empty_like(a)
+        check(self.lib.caf_xcor_c128(self._h, _dptr(a.view(np.float64)), _dptr(b.view(np.float64)), len(a),
+                                     _dptr(out.view(np.float64))))
+        return out
+
+    # -- a5 -----------------------------------------------------------------------
+    def surface_arrays(self, needle, haystack, freqs_hz, fs: int, want_surface: bool = True,
+                       dtype: str = "c128"):
+        """caf_surface as flat arrays: (surface[F,2n] | None, row_idx[F], row_val[F], CafPeak)."""
+        if len(needle) != len(haystack):
+            # caf_surface itself does not check; Xcor::run's assert trips (xcor_rustfft.rs:54-55)
+            raise AssertionError("assertion failed: a.len() == self.n")
+        fr = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        F, n = len(fr), len(needle)
+        ridx = np.zeros(F, dtype=np.uint64)
+        peak = CafPeak()
+        if dtype == "c64":
+            nd, hs = _as_c64(needle), _as_c64(haystack)
+            surf = np.empty((F, 2 * n), dtype=np.float32) if want_surface else None
+            rval = np.zeros(F, dtype=np.float32)
+            check(self.lib.caf_surface_c64(self._h, _fptr(nd.view(np.float32)), _fptr(hs.view(np.float32)), n,
+                                           _dptr(fr), F, int(fs), _fptr(surf) if want_surface else None,
+                                           _uptr(ridx), _fptr(rval), ctypes.byref(peak)))
+        elif dtype == "c128":
+            nd, hs = _as_c128(needle), _as_c128(haystack)
+            surf = np.empty((F, 2 * n), dtype=np.float64) if want_surface else None
+            rval = np.zeros(F, dtype=np.float64)
+            check(self.lib.caf_surface_c128(self._h, _dptr(nd.view(np.float64)), _dptr(hs.view(np.float64)), n,
+                                            _dptr(fr), F, int(fs), _dptr(surf) if want_surface else None,
+                                            _uptr(ridx), _dptr(rval), ctypes.byref(peak)))
+        else:
+            raise ValueError("dtype must be 'c128' or 'c64'")
+        return surf, ridx, rval, peak
+
+    def caf_surface(self, needle, haystack, freqs_hz, fs: int, want_surface: bool = True,
+                    dtype: str = "c128") -> List[CafSurfaceRow]:
+        """mod.rs:26-27 -> Vec<CafSurfaceRow> in freq-list order (like CafRustFFT /
+        the rayon collect, mod.rs:283-309)."""
+        surf, ridx, rval, _ = self.surface_arrays(needle, haystack, freqs_hz, fs, want_surface, dtype)
+        fr = np.asarray(freqs_hz, dtype=np.float64)
+        return [CafSurfaceRow(float(fr[r]), surf[r] if surf is not None else None, int(ridx[r]), float(rval[r]))
+                for r in range(len(fr))]
+
+    # -- a7 -----------------------------------------------------------------------
+    def find_peak(self, arr: Sequence[CafSurfaceRow]) -> Tuple[float, int]:
+        """mod.rs:31-42 -> (freq, xcor_peak_idx); first strictly-greater row wins,
+        an empty / all-zero surface gives (0.0, 0)."""
+        F = len(arr)
+        fr = np.array([r.freq for r in arr], dtype=np.float64)
+        ri = np.array([r.xcor_peak_idx for r in arr], dtype=np.uint64)
+        rv = np.array([r.xcor_peak_val for r in arr], dtype=np.float64)
+        peak = CafPeak()
+        check(self.lib.caf_find_peak(self._h, _dptr(fr), _uptr(ri), _dptr(rv), F, ctypes.byref(peak)))
+        return float(peak.freq), int(peak.idx)
+
+    # -- device-resident plans ----------------------------------------------------
+    def plan(self, n: int, freqs_hz, fs: int, dtype: str = "c128", row_begin: int = 0,
+             row_end: Optional[int] = None) -> "Plan":
+        return Plan(self, n, freqs_hz, fs, dtype, row_begin, row_end)
+
+
+class Plan:
+    """``caf_plan``: (n, freq list, fs, dtype[, row shard]) with device-resident tables.
+    All pointers handed to :meth:`surface_dev` are DEVICE addresses (e.g.
+    ``torch.Tensor.data_ptr()``)."""
+
+    def __init__(self, eng: Engine, n: int, freqs_hz, fs: int, dtype: str = "c128", row_begin: int = 0,
+                 row_end: Optional[int] = None):
+        self.eng = eng
+        fr = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        if row_end is None:
+            row_end = len(fr)
+        self.dtype = dtype
+        dt = {"c128": CAF_C128, "c64": CAF_C64}[dtype]
+        h = ctypes.c_void_p()
+        check(eng.lib.caf_plan_create(eng._h, int(n), _dptr(fr), len(fr), int(fs), dt, int(row_begin),
+                                      int(row_end), ctypes.byref(h)))
+        self._h = h
+        self.n, self.L = int(n), 2 * int(n)
+        self.rows = int(eng.lib.caf_plan_rows(h))
+        self.row_begin = int(row_begin)
+        self.path = eng.lib.caf_plan_path(h).decode()
+
+    def surface_dev(self, d_needle: int, d_haystack: int, batch: int, d_surface: Optional[int], d_row_idx: int,
+                    d_row_val: int, d_peak: int):
+        check(self.eng.lib.caf_surface_dev(self._h, ctypes.c_void_p(d_needle), ctypes.c_void_p(d_haystack),
+                                           int(batch), ctypes.c_void_p(d_surface or 0), ctypes.c_void_p(d_row_idx),
+                                           ctypes.c_void_p(d_row_val), ctypes.c_void_p(d_peak)))
+
+    def timing_begin(self):
+        check(self.eng.lib.caf_plan_timing_begin(self._h))
+
+    def timing_end(self) -> Tuple[float, int]:
+        ms = ctypes.c_double()
+        n = ctypes.c_uint64()
+        check(self.eng.lib.caf_plan_timing_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, int(n.value)
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.eng, "_h", None):
+            self.eng.lib.caf_plan_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default: dict = {}
+
+
+def default_engine(device: int = 0) -> Engine:
+    e = _default.get(device)
+    if e is None or e._h is None:
+        e = _default[device] = Engine(device)
+    return e
+
+
+class CafHip:
+    """``pub struct CafHip {}  impl CafSurface for CafHip`` -- associated functions
+    without ``self`` like the reference's strategies (mod.rs:67-68,118-119)."""
+
+    @staticmethod
+    def caf_surface(needle, haystack, freqs_hz, fs: int) -> List[CafSurfaceRow]:
+        return default_engine().caf_surface(needle, haystack, freqs_hz, fs)
+
+    @staticmethod
+    def find_peak(arr: Sequence[CafSurfaceRow]) -> Tuple[float, int]:
+        return default_engine().find_peak(arr)
+
+    @staticmethod
+    def apply_freq_shift(samples, freq_shift: float, fs: int) -> np.ndarray:
+        return default_engine().apply_freq_shift(samples, freq_shift, fs)
+
+
+class Xcor:
+    """xcor_rustfft::Xcor (xcor_rustfft.rs:14-93): ``new(n)``, ``run(a, b)``, ``clone()``.
+    The FFT plan for n is cached in the engine's context, which is what ``new`` /
+    ``clone`` buy in the reference."""
+
+    def __init__(self, n: int, engine: Optional[Engine] = None):
+        if n <= 0 or (n & (n - 1)):
+            raise CafError(_lib.CAF_ERR_LENGTH, f"Xcor::new: n={n} is not a power of two")
+        self.n = int(n)
+        self.engine = engine or default_engine()
+
+    def run(self, a, b) -> np.ndarray:
+        if len(a) != self.n:
+            raise AssertionError("assertion failed: a.len() == self.n")  # xcor_rustfft.rs:54
+        if len(b) != self.n:
+            raise AssertionError("assertion failed: b.len() == self.n")  # xcor_rustfft.rs:55
+        return self.engine.xcor(a, b)
+
+    def clone(self) -> "Xcor":
+        return Xcor(self.n, self.engine)

@@ -1,0 +1,642 @@
+// caf_api.hip -- C-ABI implementation (include/caf_hip.h) over the gfx950 kernels.
+// No torch types, no CPU fallback: every entry point fails loudly without a GPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/caf_hip.h"
+#include "kernels_fused4096.hpp"
+#include "kernels_generic.hpp"
+
+using namespace caf;
+
+// ------------------------------------------------------------------ errors --
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return fail(CAF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+#define KCHK() HIPCHK(hipGetLastError())
+
+static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+static size_t elem_size(int dtype) { return dtype == CAF_C128 ? 16 : 8; }
+static size_t real_size(int dtype) { return dtype == CAF_C128 ? 8 : 4; }
+
+// ----------------------------------------------------------------- structs --
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return CAF_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (bytes == 0) return CAF_OK;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return fail(CAF_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+        cap = bytes;
+        return CAF_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct caf_ctx {
+    int device = 0;
+    int cu_count = 0;
+    std::string name;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // row-independent fused tables per dtype
+    void *tw4096[2] = {nullptr, nullptr};
+    void *th[2] = {nullptr, nullptr};
+    // generic FFT twiddles per (L, dtype)
+    std::map<std::pair<size_t, int>, void *> tw_cache;
+    // host-API staging + cached plan
+    DevBuf io_needle, io_hay, io_surface, io_ridx, io_rval, io_peak, io_a, io_b;
+    caf_plan *cached = nullptr;
+    std::vector<double> cached_freqs;
+};
+
+struct caf_plan {
+    caf_ctx *ctx = nullptr;
+    size_t n = 0, L = 0;
+    int dtype = CAF_C128;
+    uint32_t fs = 0;
+    size_t nfreq_total = 0, row_begin = 0, rows = 0;
+    bool fused = false;
+    double *d_freqs = nullptr;  // this shard's slice
+    double *d_ph = nullptr;
+    // fused
+    void *d_base = nullptr, *d_step = nullptr;
+    DevBuf spec;
+    // generic
+    void *d_tw = nullptr;  // borrowed from ctx cache
+    DevBuf wx, wy, hx, hy;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+};
+
+// ------------------------------------------------------------ small helpers --
+extern "C" int caf_abi_version(void) { return CAF_ABI_VERSION; }
+extern "C" const char *caf_last_error_string(void) { return g_err; }
+
+extern "C" int caf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+template <typename T>
+static int build_fused_tables(caf_ctx *c, int dt)
+{
+    if (c->tw4096[dt]) return CAF_OK;
+    HIPCHK(hipMalloc(&c->tw4096[dt], 4096 * sizeof(cpx<T>)));
+    HIPCHK(hipMalloc(&c->th[dt], 256 * sizeof(cpx<T>)));
+    k_fused_tables<T><<<16, 256, 0, c->stream>>>((cpx<T> *)c->tw4096[dt], (cpx<T> *)c->th[dt]);
+    KCHK();
+    return CAF_OK;
+}
+
+template <typename T>
+static int get_generic_tw(caf_ctx *c, size_t L, int dt, void **out)
+{
+    auto key = std::make_pair(L, dt);
+    auto it = c->tw_cache.find(key);
+    if (it != c->tw_cache.end()) { *out = it->second; return CAF_OK; }
+    const size_t half = L / 2 ? L / 2 : 1;
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, half * sizeof(cpx<T>)));
+    k_twiddle<T><<<(unsigned)((half + 255) / 256), 256, 0, c->stream>>>((cpx<T> *)p, half, L);
+    KCHK();
+    c->tw_cache[key] = p;
+    *out = p;
+    return CAF_OK;
+}
+
+// log2(L) Stockham stages, ping-pong x<->y; returns the buffer holding the result.
+template <typename T>
+static int run_fft(caf_ctx *c, cpx<T> *x, cpx<T> *y, const cpx<T> *tw, size_t L, size_t nrows,
+                   int inverse, cpx<T> **res)
+{
+    const size_t half = L / 2;
+    for (size_t n_cur = L; n_cur >= 2; n_cur >>= 1) {
+        for (size_t r0 = 0; r0 < nrows; r0 += 65535) {
+            const size_t nr = nrows - r0 < 65535 ? nrows - r0 : 65535;
+            dim3 grid((unsigned)((half + 255) / 256), (unsigned)nr);
+            k_fft_stage<T><<<grid, 256, 0, c->stream>>>(x + r0 * L, y + r0 * L, tw, L, n_cur, inverse);
+        }
+        KCHK();
+        std::swap(x, y);
+    }
+    *res = x;
+    return CAF_OK;
+}
+
+// ------------------------------------------------------------------ context --
+extern "C" int caf_ctx_create(int device_id, caf_ctx **out)
+{
+    if (!out) return fail(CAF_ERR_BAD_ARG, "caf_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(CAF_ERR_NO_DEVICE, "no HIP device visible (%s); this engine has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev)
+        return fail(CAF_ERR_NO_DEVICE, "device id %d out of range [0,%d)", device_id, ndev);
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    caf_ctx *c = new (std::nothrow) caf_ctx;
+    if (!c) return fail(CAF_ERR_NOMEM, "out of host memory");
+    c->device = device_id;
+    c->cu_count = prop.multiProcessorCount;
+    c->name = prop.gcnArchName;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(CAF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->stream = c->own_stream;
+    *out = c;
+    return CAF_OK;
+}
+
+extern "C" int caf_plan_destroy(caf_plan *p);
+
+extern "C" int caf_ctx_destroy(caf_ctx *c)
+{
+    if (!c) return CAF_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->cached) caf_plan_destroy(c->cached);
+    for (int d = 0; d < 2; ++d) {
+        if (c->tw4096[d]) (void)hipFree(c->tw4096[d]);
+        if (c->th[d]) (void)hipFree(c->th[d]);
+    }
+    for (auto &kv : c->tw_cache) (void)hipFree(kv.second);
+    c->io_needle.release(); c->io_hay.release(); c->io_surface.release();
+    c->io_ridx.release(); c->io_rval.release(); c->io_peak.release();
+    c->io_a.release(); c->io_b.release();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return CAF_OK;
+}
+
+extern "C" int caf_ctx_set_stream(caf_ctx *c, void *hip_stream)
+{
+    if (!c) return fail(CAF_ERR_BAD_ARG, "ctx is NULL");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return CAF_OK;
+}
+
+extern "C" int caf_ctx_synchronize(caf_ctx *c)
+{
+    if (!c) return fail(CAF_ERR_BAD_ARG, "ctx is NULL");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CAF_OK;
+}
+
+extern "C" int caf_ctx_device_info(caf_ctx *c, int *cu_count, char *name_buf, size_t name_cap)
+{
+    if (!c) return fail(CAF_ERR_BAD_ARG, "ctx is NULL");
+    if (cu_count) *cu_count = c->cu_count;
+    if (name_buf && name_cap) {
+        strncpy(name_buf, c->name.c_str(), name_cap - 1);
+        name_buf[name_cap - 1] = 0;
+    }
+    return CAF_OK;
+}
+
+// --------------------------------------------------------- apply_freq_shift --
+template <typename T>
+static int apply_shift_impl(caf_ctx *c, const T *in, size_t n, double f, uint32_t fs, T *out)
+{
+    if (!c || !out || (!in && n)) return fail(CAF_ERR_BAD_ARG, "apply_freq_shift: NULL argument");
+    if (fs == 0) return fail(CAF_ERR_BAD_ARG, "apply_freq_shift: fs == 0");
+    if (n == 0) return CAF_OK;  // empty slice in, empty Vec out (mod.rs:50)
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = n * sizeof(cpx<T>);
+    int rc;
+    if ((rc = c->io_a.ensure(bytes))) return rc;
+    if ((rc = c->io_b.ensure(bytes))) return rc;
+    // same left-to-right f64 evaluation as mod.rs:54-56 (host IEEE arithmetic)
+    const double dt = 1.0 / (double)fs;
+    volatile double two_pi_f = (2.0 * 3.14159265358979323846264338327950288) * f;
+    const double ph = two_pi_f * dt;
+    HIPCHK(hipMemcpyAsync(c->io_a.p, in, bytes, hipMemcpyHostToDevice, c->stream));
+    k_apply_shift<T><<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>((const cpx<T> *)c->io_a.p, n, ph,
+                                                                         (cpx<T> *)c->io_b.p);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(out, c->io_b.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CAF_OK;
+}
+
+extern "C" int caf_apply_freq_shift_c128(caf_ctx *c, const double *in, size_t n, double f, uint32_t fs,
+                                         double *out)
+{
+    return apply_shift_impl<double>(c, in, n, f, fs, out);
+}
+extern "C" int caf_apply_freq_shift_c64(caf_ctx *c, const float *in, size_t n, double f, uint32_t fs,
+                                        float *out)
+{
+    return apply_shift_impl<float>(c, in, n, f, fs, out);
+}
+
+// -------------------------------------------------------------------- xcor --
+template <typename T>
+static int xcor_impl(caf_ctx *c, const T *a, const T *b, size_t n, T *out, int dt)
+{
+    if (!c || !a || !b || !out) return fail(CAF_ERR_BAD_ARG, "xcor: NULL argument");
+    if (!is_pow2(n)) return fail(CAF_ERR_LENGTH, "xcor: n=%zu is not a power of two", n);
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = n * sizeof(cpx<T>);
+    int rc;
+    if ((rc = c->io_a.ensure(2 * bytes))) return rc;
+    if ((rc = c->io_b.ensure(2 * bytes))) return rc;
+    void *tw = nullptr;
+    if ((rc = get_generic_tw<T>(c, n, dt, &tw))) return rc;
+    cpx<T> *x = (cpx<T> *)c->io_a.p, *y = (cpx<T> *)c->io_b.p;
+    HIPCHK(hipMemcpyAsync(x, a, bytes, hipMemcpyHostToDevice, c->stream));      // row 0 = a
+    HIPCHK(hipMemcpyAsync(x + n, b, bytes, hipMemcpyHostToDevice, c->stream));  // row 1 = b
+    cpx<T> *spec = nullptr;
+    if ((rc = run_fft<T>(c, x, y, (const cpx<T> *)tw, n, 2, 0, &spec))) return rc;  // xcor_rustfft.rs:58-61
+    cpx<T> *other = spec == x ? y : x;
+    k_mul_conj<T><<<dim3((unsigned)((n + 255) / 256), 1), 256, 0, c->stream>>>(spec, spec + n, n, 1);  // :64-73
+    KCHK();
+    cpx<T> *res = nullptr;
+    if ((rc = run_fft<T>(c, spec + n, other + n, (const cpx<T> *)tw, n, 1, 1, &res))) return rc;  // :76
+    HIPCHK(hipMemcpyAsync(out, res, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CAF_OK;
+}
+
+extern "C" int caf_xcor_c128(caf_ctx *c, const double *a, const double *b, size_t n, double *out)
+{
+    return xcor_impl<double>(c, a, b, n, out, CAF_C128);
+}
+extern "C" int caf_xcor_c64(caf_ctx *c, const float *a, const float *b, size_t n, float *out)
+{
+    return xcor_impl<float>(c, a, b, n, out, CAF_C64);
+}
+
+// -------------------------------------------------------------------- plan --
+template <typename T>
+static int plan_build_tables(caf_plan *p)
+{
+    caf_ctx *c = p->ctx;
+    const int dt = p->dtype;
+    int rc;
+    if (p->fused) {
+        if ((rc = build_fused_tables<T>(c, dt))) return rc;
+        const size_t nr = p->rows + 1;  // +1: the f = 0 row for the haystack transform
+        HIPCHK(hipMalloc(&p->d_base, nr * 512 * sizeof(cpx<T>)));
+        HIPCHK(hipMalloc(&p->d_step, nr * 32 * sizeof(cpx<T>)));
+        const size_t threads = nr * 512;
+        k_fused_phasors<T><<<(unsigned)((threads + 255) / 256), 256, 0, c->stream>>>(
+            p->d_ph, (int)p->rows, (cpx<T> *)p->d_base, (cpx<T> *)p->d_step);
+        KCHK();
+    } else {
+        if ((rc = get_generic_tw<T>(c, p->L, dt, &p->d_tw))) return rc;
+    }
+    return CAF_OK;
+}
+
+extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, size_t nfreq, uint32_t fs,
+                               int dtype, size_t row_begin, size_t row_end, caf_plan **out)
+{
+    if (!c || !out) return fail(CAF_ERR_BAD_ARG, "plan_create: NULL argument");
+    *out = nullptr;
+    if (!freqs_hz && nfreq) return fail(CAF_ERR_BAD_ARG, "plan_create: freqs_hz is NULL");
+    if (dtype != CAF_C128 && dtype != CAF_C64) return fail(CAF_ERR_BAD_ARG, "plan_create: bad dtype %d", dtype);
+    if (!is_pow2(n)) return fail(CAF_ERR_LENGTH, "caf_surface: n=%zu is not a power of two >= 1", n);
+    if (fs == 0) return fail(CAF_ERR_BAD_ARG, "plan_create: fs == 0");
+    if (row_begin > row_end || row_end > nfreq)
+        return fail(CAF_ERR_BAD_ARG, "plan_create: bad shard [%zu,%zu) of %zu", row_begin, row_end, nfreq);
+    if (row_end - row_begin > 0x7fffffffu / 2) return fail(CAF_ERR_BAD_ARG, "plan_create: too many rows");
+    HIPCHK(hipSetDevice(c->device));
+    caf_plan *p = new (std::nothrow) caf_plan;
+    if (!p) return fail(CAF_ERR_NOMEM, "out of host memory");
+    p->ctx = c;
+    p->n = n;
+    p->L = 2 * n;  // mod.rs:130-131
+    p->dtype = dtype;
+    p->fs = fs;
+    p->nfreq_total = nfreq;
+    p->row_begin = row_begin;
+    p->rows = row_end - row_begin;
+    p->fused = (n == (size_t)F_N);
+    int rc = CAF_OK;
+    auto bail = [&](int code) { caf_plan_destroy(p); return code; };
+    if (p->rows) {
+        hipError_t e;
+        if ((e = hipMalloc((void **)&p->d_freqs, p->rows * sizeof(double))) != hipSuccess ||
+            (e = hipMalloc((void **)&p->d_ph, p->rows * sizeof(double))) != hipSuccess)
+            return bail(fail(CAF_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)));
+        // pageable H2D on a stream is synchronous w.r.t. the host buffer: safe to borrow
+        if ((e = hipMemcpyAsync(p->d_freqs, freqs_hz + row_begin, p->rows * sizeof(double),
+                                hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+            return bail(fail(CAF_ERR_HIP, "hipMemcpyAsync(freqs): %s", hipGetErrorString(e)));
+        k_phase<<<(unsigned)((p->rows + 255) / 256), 256, 0, c->stream>>>(p->d_freqs, (int)p->rows, fs, p->d_ph);
+        if ((e = hipGetLastError()) != hipSuccess)
+            return bail(fail(CAF_ERR_HIP, "k_phase launch: %s", hipGetErrorString(e)));
+    }
+    rc = dtype == CAF_C128 ? plan_build_tables<double>(p) : plan_build_tables<float>(p);
+    if (rc) return bail(rc);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return bail(fail(CAF_ERR_HIP, "plan tables: %s", hipGetErrorString(e)));
+    *out = p;
+    return CAF_OK;
+}
+
+extern "C" int caf_plan_destroy(caf_plan *p)
+{
+    if (!p) return CAF_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->d_freqs) (void)hipFree(p->d_freqs);
+    if (p->d_ph) (void)hipFree(p->d_ph);
+    if (p->d_base) (void)hipFree(p->d_base);
+    if (p->d_step) (void)hipFree(p->d_step);
+    p->spec.release(); p->wx.release(); p->wy.release(); p->hx.release(); p->hy.release();
+    for (auto ev : p->ev) (void)hipEventDestroy(ev);
+    if (p->ctx->cached == p) p->ctx->cached = nullptr;
+    delete p;
+    return CAF_OK;
+}
+
+extern "C" const char *caf_plan_path(const caf_plan *p) { return !p ? "" : p->fused ? "fused4096" : "generic"; }
+extern "C" size_t caf_plan_rows(const caf_plan *p) { return p ? p->rows : 0; }
+
+static int timing_mark(caf_plan *p)
+{
+    if (!p->timing) return CAF_OK;
+    if (p->ev_used == p->ev.size()) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreate(&ev));
+        p->ev.push_back(ev);
+    }
+    HIPCHK(hipEventRecord(p->ev[p->ev_used++], p->ctx->stream));
+    return CAF_OK;
+}
+
+extern "C" int caf_plan_timing_begin(caf_plan *p)
+{
+    if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
+    p->timing = true;
+    p->ev_used = 0;
+    return CAF_OK;
+}
+
+extern "C" int caf_plan_timing_end(caf_plan *p, double *ms_total, uint64_t *launches)
+{
+    if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));
+        tot += ms;
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = p->ev_used / 2;
+    p->timing = false;
+    p->ev_used = 0;
+    return CAF_OK;
+}
+
+// ------------------------------------------------------------ surface (dev) --
+template <typename T>
+static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch,
+                             void *d_surface, uint64_t *d_ridx, void *d_rval)
+{
+    caf_ctx *c = p->ctx;
+    int rc;
+    if ((rc = p->spec.ensure(batch * 2 * 16 * 256 * sizeof(cpx<T>)))) return rc;
+    FusedArgs<T> a;
+    a.ph_base = (const cpx<T> *)p->d_base;
+    a.ph_step = (const cpx<T> *)p->d_step;
+    a.tab.tw4096 = (const cpx<T> *)c->tw4096[p->dtype];
+    a.tab.th = (const cpx<T> *)c->th[p->dtype];
+    a.spec = (cpx<T> *)p->spec.p;
+    a.rows = (int)p->rows;
+    a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr;
+    // haystack spectrum, once per surface (the reference recomputes it per row,
+    // xcor_rustfft.rs:58-59)
+    a.sig = (const cpx<T> *)d_hay;
+    a.total = (int)batch;
+    k_fused_rows<T, true><<<(unsigned)batch, F_THREADS, 0, c->stream>>>(a);
+    KCHK();
+    const size_t total = batch * p->rows;
+    if (total == 0) return CAF_OK;
+    a.sig = (const cpx<T> *)d_needle;
+    a.total = (int)total;
+    a.surface = (T *)d_surface;
+    a.row_idx = d_ridx;
+    a.row_val = (T *)d_rval;
+    const size_t per_cu = fused_lds_bytes<T>() * 2 <= 160 * 1024 ? 2 : 1;
+    const size_t cap = (size_t)c->cu_count * per_cu;
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
+    if ((rc = timing_mark(p))) return rc;
+    k_fused_rows<T, false><<<grid, F_THREADS, 0, c->stream>>>(a);
+    KCHK();
+    if ((rc = timing_mark(p))) return rc;
+    return CAF_OK;
+}
+
+template <typename T>
+static int surface_dev_generic(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch,
+                               void *d_surface, uint64_t *d_ridx, void *d_rval)
+{
+    caf_ctx *c = p->ctx;
+    const size_t L = p->L, n = p->n, rows = p->rows, total = batch * rows;
+    int rc;
+    if ((rc = p->hx.ensure(batch * L * sizeof(cpx<T>)))) return rc;
+    if ((rc = p->hy.ensure(batch * L * sizeof(cpx<T>)))) return rc;
+    const cpx<T> *tw = (const cpx<T> *)p->d_tw;
+    const unsigned gx = (unsigned)((L + 255) / 256);
+    // H = FFT(haystack ++ zeros)   (mod.rs:131, xcor_rustfft.rs:58-59 hoisted)
+    for (size_t b0 = 0; b0 < batch; b0 += 65535) {
+        const size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        k_mix_pad<T><<<dim3(gx, (unsigned)nb), 256, 0, c->stream>>>((const cpx<T> *)d_hay + b0 * n, n, L, nullptr, 1,
+                                                                   (cpx<T> *)p->hx.p + b0 * L);
+    }
+    KCHK();
+    cpx<T> *H = nullptr;
+    if ((rc = run_fft<T>(c, (cpx<T> *)p->hx.p, (cpx<T> *)p->hy.p, tw, L, batch, 0, &H))) return rc;
+    if (total == 0) return CAF_OK;
+    if ((rc = p->wx.ensure(total * L * sizeof(cpx<T>)))) return rc;
+    if ((rc = p->wy.ensure(total * L * sizeof(cpx<T>)))) return rc;
+    cpx<T> *x = (cpx<T> *)p->wx.p, *y = (cpx<T> *)p->wy.p;
+    if ((rc = timing_mark(p))) return rc;
+    // shifted = apply_freq_shift(needle ++ zeros)   (mod.rs:130,138); one batch entry per launch
+    for (size_t b = 0; b < batch; ++b)
+        for (size_t r0 = 0; r0 < rows; r0 += 65535) {
+            const size_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+            k_mix_pad<T><<<dim3(gx, (unsigned)nr), 256, 0, c->stream>>>(
+                (const cpx<T> *)d_needle + b * n, n, L, p->d_ph + r0, nr, x + (b * rows + r0) * L);
+        }
+    KCHK();
+    cpx<T> *S = nullptr;
+    if ((rc = run_fft<T>(c, x, y, tw, L, total, 0, &S))) return rc;  // xcor_rustfft.rs:60-61
+    cpx<T> *other = S == x ? y : x;
+    for (size_t b = 0; b < batch; ++b)
+        for (size_t r0 = 0; r0 < rows; r0 += 65535) {
+            const size_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+            k_mul_conj<T><<<dim3(gx, (unsigned)nr), 256, 0, c->stream>>>(H + b * L, S + (b * rows + r0) * L, L, nr);
+        }
+    KCHK();
+    cpx<T> *res = nullptr;
+    if ((rc = run_fft<T>(c, S, other, tw, L, total, 1, &res))) return rc;  // xcor_rustfft.rs:76
+    k_mag_argmax<T><<<(unsigned)total, 256, 0, c->stream>>>(res, L, (T *)d_surface, d_ridx, (T *)d_rval);
+    KCHK();
+    if ((rc = timing_mark(p))) return rc;
+    return CAF_OK;
+}
+
+extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch,
+                               void *d_surface, uint64_t *d_ridx, void *d_rval, caf_peak *d_peak)
+{
+    if (!p || !d_needle || !d_hay || !d_peak) return fail(CAF_ERR_BAD_ARG, "caf_surface_dev: NULL argument");
+    if (p->rows && (!d_ridx || !d_rval)) return fail(CAF_ERR_BAD_ARG, "caf_surface_dev: row outputs are NULL");
+    if (batch == 0) return CAF_OK;
+    if (batch * (p->rows ? p->rows : 1) > 0x7fffffffu) return fail(CAF_ERR_BAD_ARG, "caf_surface_dev: batch too large");
+    caf_ctx *c = p->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if (p->dtype == CAF_C128)
+        rc = p->fused ? surface_dev_fused<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+                      : surface_dev_generic<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
+    else
+        rc = p->fused ? surface_dev_fused<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+                      : surface_dev_generic<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
+    if (rc) return rc;
+    // find_peak (mod.rs:31-42)
+    if (p->dtype == CAF_C128)
+        k_peak<double><<<(unsigned)batch, 256, 0, c->stream>>>(p->d_freqs, d_ridx, (const double *)d_rval, (int)p->rows,
+                                                               (int64_t)p->row_begin, d_peak);
+    else
+        k_peak<float><<<(unsigned)batch, 256, 0, c->stream>>>(p->d_freqs, d_ridx, (const float *)d_rval, (int)p->rows,
+                                                              (int64_t)p->row_begin, d_peak);
+    KCHK();
+    return CAF_OK;
+}
+
+// ----------------------------------------------------------- surface (host) --
+static int get_cached_plan(caf_ctx *c, size_t n, const double *freqs, size_t nfreq, uint32_t fs, int dtype,
+                           caf_plan **out)
+{
+    caf_plan *p = c->cached;
+    if (p && p->n == n && p->fs == fs && p->dtype == dtype && p->nfreq_total == nfreq && p->row_begin == 0 &&
+        p->rows == nfreq && c->cached_freqs.size() == nfreq &&
+        (nfreq == 0 || memcmp(c->cached_freqs.data(), freqs, nfreq * sizeof(double)) == 0)) {
+        *out = p;
+        return CAF_OK;
+    }
+    if (p) { caf_plan_destroy(p); c->cached = nullptr; }
+    int rc = caf_plan_create(c, n, freqs, nfreq, fs, dtype, 0, nfreq, &p);
+    if (rc) return rc;
+    c->cached = p;
+    c->cached_freqs.assign(freqs, freqs + nfreq);
+    *out = p;
+    return CAF_OK;
+}
+
+template <typename T>
+static int surface_host_impl(caf_ctx *c, const T *needle, const T *hay, size_t n, const double *freqs,
+                             size_t nfreq, uint32_t fs, T *surface, uint64_t *row_idx, T *row_val,
+                             caf_peak *peak, int dtype)
+{
+    if (!c || !needle || !hay || !peak) return fail(CAF_ERR_BAD_ARG, "caf_surface: NULL argument");
+    if (!freqs && nfreq) return fail(CAF_ERR_BAD_ARG, "caf_surface: freqs_hz is NULL");
+    if (!is_pow2(n)) return fail(CAF_ERR_LENGTH, "caf_surface: n=%zu is not a power of two >= 1", n);
+    HIPCHK(hipSetDevice(c->device));
+    caf_plan *p = nullptr;
+    int rc = get_cached_plan(c, n, freqs, nfreq, fs, dtype, &p);
+    if (rc) return rc;
+    const size_t L = 2 * n, in_bytes = n * sizeof(cpx<T>);
+    if ((rc = c->io_needle.ensure(in_bytes))) return rc;
+    if ((rc = c->io_hay.ensure(in_bytes))) return rc;
+    if ((rc = c->io_ridx.ensure((nfreq ? nfreq : 1) * sizeof(uint64_t)))) return rc;
+    if ((rc = c->io_rval.ensure((nfreq ? nfreq : 1) * sizeof(T)))) return rc;
+    if ((rc = c->io_peak.ensure(sizeof(caf_peak)))) return rc;
+    if (surface && nfreq && (rc = c->io_surface.ensure(nfreq * L * sizeof(T)))) return rc;
+    HIPCHK(hipMemcpyAsync(c->io_needle.p, needle, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->io_hay.p, hay, in_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = caf_surface_dev(p, c->io_needle.p, c->io_hay.p, 1, surface && nfreq ? c->io_surface.p : nullptr,
+                         (uint64_t *)c->io_ridx.p, c->io_rval.p, (caf_peak *)c->io_peak.p);
+    if (rc) return rc;
+    if (surface && nfreq)
+        HIPCHK(hipMemcpyAsync(surface, c->io_surface.p, nfreq * L * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    if (row_idx && nfreq)
+        HIPCHK(hipMemcpyAsync(row_idx, c->io_ridx.p, nfreq * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (row_val && nfreq)
+        HIPCHK(hipMemcpyAsync(row_val, c->io_rval.p, nfreq * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(peak, c->io_peak.p, sizeof(caf_peak), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CAF_OK;
+}
+
+extern "C" int caf_surface_c128(caf_ctx *c, const double *needle, const double *hay, size_t n,
+                                const double *freqs, size_t nfreq, uint32_t fs, double *surface,
+                                uint64_t *row_idx, double *row_val, caf_peak *peak)
+{
+    return surface_host_impl<double>(c, needle, hay, n, freqs, nfreq, fs, surface, row_idx, row_val, peak, CAF_C128);
+}
+
+extern "C" int caf_surface_c64(caf_ctx *c, const float *needle, const float *hay, size_t n, const double *freqs,
+                               size_t nfreq, uint32_t fs, float *surface, uint64_t *row_idx, float *row_val,
+                               caf_peak *peak)
+{
+    return surface_host_impl<float>(c, needle, hay, n, freqs, nfreq, fs, surface, row_idx, row_val, peak, CAF_C64);
+}
+
+// --------------------------------------------------------------- find_peak --
+extern "C" int caf_find_peak(caf_ctx *c, const double *freqs, const uint64_t *row_idx, const double *row_val,
+                             size_t nfreq, caf_peak *peak)
+{
+    if (!c || !peak) return fail(CAF_ERR_BAD_ARG, "caf_find_peak: NULL argument");
+    if (nfreq && (!freqs || !row_idx || !row_val)) return fail(CAF_ERR_BAD_ARG, "caf_find_peak: NULL rows");
+    if (nfreq > 0x7fffffffu) return fail(CAF_ERR_BAD_ARG, "caf_find_peak: too many rows");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    const size_t m = nfreq ? nfreq : 1;
+    if ((rc = c->io_a.ensure(m * sizeof(double)))) return rc;
+    if ((rc = c->io_ridx.ensure(m * sizeof(uint64_t)))) return rc;
+    if ((rc = c->io_rval.ensure(m * sizeof(double)))) return rc;
+    if ((rc = c->io_peak.ensure(sizeof(caf_peak)))) return rc;
+    if (nfreq) {
+        HIPCHK(hipMemcpyAsync(c->io_a.p, freqs, nfreq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->io_ridx.p, row_idx, nfreq * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->io_rval.p, row_val, nfreq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    k_peak<double><<<1, 256, 0, c->stream>>>((const double *)c->io_a.p, (const uint64_t *)c->io_ridx.p,
+                                             (const double *)c->io_rval.p, (int)nfreq, 0, (caf_peak *)c->io_peak.p);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(peak, c->io_peak.p, sizeof(caf_peak), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CAF_OK;
+}

@@ -1,0 +1,156 @@
+/*
+ * caf_hip.h -- C ABI of the MI355X (gfx950) Cross Ambiguity Function engine.
+ *
+ * This is the drop-in boundary for the caf_rust hot path.  The reference has no
+ * FFI today; its extension point is "one more `impl CafSurface for X`"
+ * (caf_rust/src/caf/mod.rs:23-66, pattern at :67-68,:118-119,:388-389).  An
+ * eighth backend `CafHip` binds exactly the entry points below (the Rust stub
+ * is in INTEGRATION.md).  Each entry point cites the reference interface it
+ * replaces.
+ *
+ * Conventions
+ *   - complex slices are interleaved {re, im}: `const double*` of 2*n doubles is
+ *     a `&[Complex64]` (num_complex::Complex64 is #[repr(C)] {re:f64, im:f64});
+ *     the `_c64` twins take interleaved floats (numpy complex64, the on-disk
+ *     ".c64" format of caf_rust/src/utils.rs:10-35).
+ *   - every function returns an int status (CAF_OK == 0); nothing unwinds across
+ *     the boundary.  The reference panics instead (assert!/unwrap,
+ *     xcor_rustfft.rs:54-55); a host shim turns non-zero into a panic.
+ *   - outputs are caller-allocated; inputs are borrowed for the call.
+ *   - a context is bound to one GPU and is NOT thread-safe; use one per thread.
+ *   - lengths: n must be a power of two >= 1 (xcor_rustfft.rs:2 "Assumes
+ *     equal-length, power of 2"); caf_surface pads to 2n itself (mod.rs:130-131).
+ *   - there is NO CPU fallback: without a usable HIP device every call fails
+ *     with CAF_ERR_NO_DEVICE / CAF_ERR_HIP.
+ */
+#ifndef CAF_HIP_H
+#define CAF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAF_ABI_VERSION 1
+
+enum caf_status {
+    CAF_OK = 0,
+    CAF_ERR_BAD_ARG = 1,   /* null pointer / bad enum */
+    CAF_ERR_LENGTH = 2,    /* n == 0 or not a power of two (xcor_rustfft.rs:54-55 assert) */
+    CAF_ERR_HIP = 3,       /* a HIP runtime call failed; see caf_last_error_string() */
+    CAF_ERR_NOMEM = 4,
+    CAF_ERR_NO_DEVICE = 5, /* no gfx950 device visible / device id out of range */
+    CAF_ERR_STATE = 6      /* call order violated (e.g. stream used after destroy) */
+};
+
+enum caf_dtype {
+    CAF_C128 = 0, /* complex128 in, f64 |.|^2 out  (the reference's arithmetic) */
+    CAF_C64 = 1   /* complex64 in,  f32 |.|^2 out  (phase still computed in f64) */
+};
+
+typedef struct caf_ctx caf_ctx;
+typedef struct caf_plan caf_plan;
+
+/* Global peak record, mod.rs:31-42 (find_peak).  row == -1 means "no row had a
+ * peak > 0": freq = 0.0, idx = 0, val = 0.0 exactly like the reference's
+ * initial `max` (mod.rs:32-35). */
+typedef struct caf_peak {
+    double val;   /* xcor_peak_val of the winning row (f32 paths: widened) */
+    double freq;  /* CafSurfaceRow.freq of the winning row */
+    uint64_t idx; /* xcor_peak_idx: sample index in [0, 2n) */
+    int64_t row;  /* position in the freq list (global position for shards) */
+} caf_peak;
+
+int caf_abi_version(void);
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char *caf_last_error_string(void);
+/* Number of HIP devices visible; 0 without a GPU (never touches the GPU state
+ * beyond counting). */
+int caf_device_count(void);
+
+/* ---- context ----------------------------------------------------------- */
+int caf_ctx_create(int device_id, caf_ctx **out);
+int caf_ctx_destroy(caf_ctx *ctx);
+/* Run all work of this context on a caller-owned hipStream_t (e.g. torch's
+ * current stream).  NULL restores the context's own stream. */
+int caf_ctx_set_stream(caf_ctx *ctx, void *hip_stream);
+int caf_ctx_synchronize(caf_ctx *ctx);
+/* Device facts for reports: CU count and name (buf may be NULL). */
+int caf_ctx_device_info(caf_ctx *ctx, int *cu_count, char *name_buf, size_t name_cap);
+
+/* ---- a1: CafSurface::apply_freq_shift, mod.rs:46-65 -------------------------
+ * out[i] = in[i] * e^{j*ph*i}, ph = ((2*PI)*freq_shift)*(1/fs).  The reference
+ * builds the phasor by a sequential recurrence; here every phasor is evaluated
+ * directly from the f64 phase (difference <= ~2e-14 absolute over 8192 samples). */
+int caf_apply_freq_shift_c128(caf_ctx *ctx, const double *in, size_t n,
+                              double freq_shift, uint32_t fs, double *out);
+int caf_apply_freq_shift_c64(caf_ctx *ctx, const float *in, size_t n,
+                             double freq_shift, uint32_t fs, float *out);
+
+/* ---- a2-a4: xcor_rustfft::Xcor::{new,run}, xcor_rustfft.rs:29-78 ------------
+ * out[k] = sum_m a[(m+k) mod n] * conj(b[m]) = IFFT(FFT(a)*conj(FFT(b))/n)
+ * (unnormalised inverse).  Plans are cached inside the context per n, which is
+ * what Xcor::new/clone provide. */
+int caf_xcor_c128(caf_ctx *ctx, const double *a, const double *b, size_t n, double *out);
+int caf_xcor_c64(caf_ctx *ctx, const float *a, const float *b, size_t n, float *out);
+
+/* ---- a5-a7: CafSurface::caf_surface + find_peak, mod.rs:26-42,121-166 -------
+ * needle, haystack: n complex each (equal length, mod.rs / xcor assert).
+ * surface : nfreq * 2n values row-major (row r = freqs_hz[r]) or NULL to skip
+ *           the device->host copy of the 26 MB surface.
+ * row_idx / row_val : nfreq entries (CafSurfaceRow.xcor_peak_idx/_val), may be NULL.
+ * peak    : find_peak() of the rows in list order (first strictly-greater wins).
+ * Host pointers; blocks until the results are in host memory. */
+int caf_surface_c128(caf_ctx *ctx, const double *needle, const double *haystack,
+                     size_t n, const double *freqs_hz, size_t nfreq, uint32_t fs,
+                     double *surface, uint64_t *row_idx, double *row_val,
+                     caf_peak *peak);
+int caf_surface_c64(caf_ctx *ctx, const float *needle, const float *haystack,
+                    size_t n, const double *freqs_hz, size_t nfreq, uint32_t fs,
+                    float *surface, uint64_t *row_idx, float *row_val,
+                    caf_peak *peak);
+
+/* find_peak over caller-held rows (mod.rs:31-42), evaluated on the device with
+ * the same kernel the fused path uses. */
+int caf_find_peak(caf_ctx *ctx, const double *freqs_hz, const uint64_t *row_idx,
+                  const double *row_val, size_t nfreq, caf_peak *peak);
+
+/* ---- device-resident path (bench, streaming, multi-GPU shards) --------------
+ * A plan fixes (n, freq list, fs, dtype) like Xcor::new fixes n, and owns the
+ * per-row phasor tables.  [row_begin,row_end) selects this GPU's contiguous
+ * shard of the freq list; peak.row is reported in GLOBAL list
+ * positions so a min over equal peaks preserves "first row wins". */
+int caf_plan_create(caf_ctx *ctx, size_t n, const double *freqs_hz, size_t nfreq,
+                    uint32_t fs, int dtype, size_t row_begin, size_t row_end,
+                    caf_plan **out);
+int caf_plan_destroy(caf_plan *plan);
+/* Name of the kernel path the plan selected: "fused4096" or "generic". */
+const char *caf_plan_path(const caf_plan *plan);
+size_t caf_plan_rows(const caf_plan *plan);
+
+/* Enqueue `batch` surfaces on the context's stream and return immediately.
+ * ALL pointers are device pointers (hipMalloc / torch tensors):
+ *   d_needle, d_haystack : [batch][n] complex (dtype of the plan)
+ *   d_surface            : [batch][rows][2n] real or NULL (skip the store)
+ *   d_row_idx            : [batch][rows] uint64
+ *   d_row_val            : [batch][rows] real
+ *   d_peak               : [batch] caf_peak
+ * rows = row_end - row_begin of the plan. */
+int caf_surface_dev(caf_plan *plan, const void *d_needle, const void *d_haystack,
+                    size_t batch, void *d_surface, uint64_t *d_row_idx,
+                    void *d_row_val, caf_peak *d_peak);
+
+/* HIP-event timing of the dominant kernel for bench.py's roofline object:
+ * start/stop events are recorded on the plan's stream around the row-kernel
+ * launches of every caf_surface_dev call between begin and end; end
+ * synchronises and returns the accumulated kernel milliseconds and the number
+ * of launches. */
+int caf_plan_timing_begin(caf_plan *plan);
+int caf_plan_timing_end(caf_plan *plan, double *kernel_ms_total, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAF_HIP_H */

@@ -1,0 +1,302 @@
+"""GPU parity tests: every call goes through the C ABI (libcaf_hip.so) and is
+compared with the CPU oracle / the committed golden vectors.
+
+Bars (BASELINE.json north_star):
+  * argmax (freq, idx): exact equality with the reference's known answers
+  * f64 surface: |d| <= 1e-6 * max(surface)     (per-element relative is meaningless:
+    the surface has exact zeros and entries 1e-20 below the peak)
+  * f32 surface: |d| <= 1e-3 * max(surface)
+"""
+import numpy as np
+import pytest
+
+from conftest import DATA
+
+pytestmark = pytest.mark.gpu
+
+FS = 48000
+TOL64 = 1e-6
+TOL32 = 1e-3
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import caf_cookoff_amd as caf
+    assert caf.LIB_PATH.exists(), "HIP extension missing: the product path must not run without it"
+    e = caf.Engine(0)
+    cu, name = e.device_info()
+    print(f"device: {name}, {cu} CUs")
+    yield e
+    e.close()
+
+
+def _pair(oracle, k):
+    return oracle.load_pair(DATA, f"chirp_{k}_raw.c64", oracle.KATS[k][1])
+
+
+# ----------------------------------------------------------------- KATs ------
+def _kats():
+    from oracle import caf_oracle as O
+    return O.KATS
+
+
+@pytest.mark.parametrize("kat", _kats(), ids=lambda k: f"chirp{k[0]}")
+def test_reference_kats_fused_f64(kat, eng, oracle, golden):
+    """caf_rust/tests/test.rs:14-316 through the fused n=4096 kernel."""
+    import caf_cookoff_amd as caf
+    k, hf, (s, e, st), exp = kat
+    nd, hs = caf.load_files(DATA / f"chirp_{k}_raw.c64", DATA / hf)
+    fr = caf.gen_float_shifts(s, e, st)
+    surface = eng.caf_surface(nd, hs, fr, FS, want_surface=False)
+    freq, idx = eng.find_peak(surface)
+    assert freq == exp[0] and idx == exp[1]  # assert_eq! semantics: exact
+    ridx = np.array([r.xcor_peak_idx for r in surface], dtype=np.uint64)
+    rval = np.array([r.xcor_peak_val for r in surface])
+    g = golden[f"kat{k}_row_val"]
+    assert np.array_equal(ridx, golden[f"kat{k}_row_idx"])
+    assert np.max(np.abs(rval - g)) <= TOL64 * g.max()
+
+
+def test_bench_config_f64_golden(eng, oracle, golden, manifest):
+    """BASELINE configs[1]: 400x8192 c128, argmax equality + surface parity."""
+    fr = oracle.bench_shifts()
+    for k in ("0", "4"):
+        m = manifest["bench"][k]
+        nd, hs = oracle.load_pair(DATA, m["needle"], m["haystack"])
+        surf, ridx, rval, peak = eng.surface_arrays(nd, hs, fr, FS)
+        assert (peak.freq, peak.idx) == (m["best_freq"], m["best_idx"])
+        assert peak.val == rval[int(peak.row)] and fr[int(peak.row)] == peak.freq
+        assert np.array_equal(ridx, golden[f"bench{k}_row_idx"])
+        tol = TOL64 * m["surface_max"]
+        assert np.max(np.abs(rval - golden[f"bench{k}_row_val"])) <= tol
+        assert np.max(np.abs(surf[manifest["full_rows"]] - golden[f"bench{k}_rows"])) <= tol
+        assert np.max(np.abs(surf.reshape(-1)[::manifest["stride"]] - golden[f"bench{k}_strided"])) <= tol
+        # row peaks are consistent with the stored surface
+        assert np.array_equal(surf.argmax(axis=1).astype(np.uint64), ridx)
+        assert np.array_equal(surf.max(axis=1), rval)
+        err = np.max(np.abs(surf[manifest["full_rows"]] - golden[f"bench{k}_rows"])) / m["surface_max"]
+        print(f"chirp_{k} bench: max|d|/max = {err:.3e}")
+
+
+def test_full_surface_vs_c_oracle(eng, oracle, coracle):
+    """Whole 400x8192 surface against the C restatement (own FFT)."""
+    fr = oracle.bench_shifts()
+    nd, hs = _pair(oracle, 9)
+    surf, ridx, rval, peak = eng.surface_arrays(nd, hs, fr, FS)
+    osurf, oidx, oval = coracle.caf_surface(nd, hs, fr, FS, hoist=True, nthreads=8)
+    assert np.max(np.abs(surf - osurf)) <= TOL64 * osurf.max()
+    assert np.array_equal(ridx, oidx)
+    assert (peak.freq, peak.idx) == coracle.find_peak(fr, oidx, oval)
+
+
+def test_fused_vs_generic_path_agree(eng, oracle):
+    """The same rows through both kernel paths (generic path forced via a plan on
+    half-length inputs is a different problem, so compare on n=4096 by calling the
+    generic kernels through xcor + apply_freq_shift)."""
+    nd, hs = _pair(oracle, 4)
+    fr = np.array([82.9, -13.0])
+    surf, ridx, rval, _ = eng.surface_arrays(nd, hs, fr, FS)
+    z = np.zeros(4096, dtype=np.complex128)
+    for r, f in enumerate(fr):
+        shifted = eng.apply_freq_shift(np.concatenate([nd, z]), f, FS)   # mod.rs:130,138
+        c = eng.xcor(np.concatenate([hs, z]), shifted)                   # mod.rs:139
+        mag = c.real ** 2 + c.imag ** 2
+        assert np.max(np.abs(mag - surf[r])) <= TOL64 * mag.max()
+        assert int(np.argmax(mag)) == int(ridx[r])
+
+
+# ------------------------------------------------------------- generic path --
+@pytest.mark.parametrize("n", [1, 2, 8, 64, 512, 2048, 8192])
+def test_generic_sizes_vs_oracle(n, eng, oracle):
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    lag = n // 3
+    b = np.roll(a, lag) * np.exp(2j * np.pi * 37.5 * np.arange(n) / FS) + 0.01 * rng.standard_normal(n)
+    fr = np.array([-75.0, 0.0, 37.5, 75.0, 112.5])
+    surf, ridx, rval, peak = eng.surface_arrays(a, b, fr, FS)
+    osurf, oidx, oval = oracle.np_caf_surface(a, b, fr, FS)
+    assert surf.shape == (5, 2 * n)
+    assert np.max(np.abs(surf - osurf)) <= TOL64 * osurf.max()
+    assert np.array_equal(ridx, oidx)
+    assert (peak.freq, peak.idx) == oracle.np_find_peak(fr, oidx, oval)
+
+
+@pytest.mark.parametrize("n", [8, 64, 4096])
+def test_apply_freq_shift_golden(n, eng, golden):
+    """mod.rs:46-65 vectors (recurrence) vs direct-phasor kernel: <= 1e-12 absolute
+    on O(1) data (the recurrence itself drifts ~2e-14 from the exact phasor)."""
+    a = golden[f"vec{n}_a"]
+    for tag, f in (("77p77", 77.77), ("m12p5", -12.5)):
+        out = eng.apply_freq_shift(a, f, FS)
+        g = golden[f"vec{n}_shift_{tag}"]
+        assert out[0] == a[0]  # sample 0 is multiplied by 1+0j (mod.rs:57-59)
+        assert np.max(np.abs(out - g)) <= 1e-12 * max(1.0, np.max(np.abs(g)))
+
+
+@pytest.mark.parametrize("n", [8, 64, 4096])
+def test_xcor_golden(n, eng, golden):
+    import caf_cookoff_amd as caf
+    a, b = golden[f"vec{n}_a"], golden[f"vec{n}_b"]
+    x = caf.Xcor(n, eng)
+    out = x.clone().run(a, b)
+    g = golden[f"vec{n}_xcor"]
+    assert np.max(np.abs(out - g)) <= 1e-12 * np.max(np.abs(g))
+
+
+def test_xcor_size_independent_properties(eng):
+    """Full-size properties: circular-shift covariance and conjugate symmetry
+    xcor(a,b)[k] == conj(xcor(b,a)[-k]); linearity in a."""
+    rng = np.random.default_rng(5)
+    n = 8192
+    a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    c = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    xab = eng.xcor(a, b)
+    scale = np.max(np.abs(xab))
+    assert np.max(np.abs(eng.xcor(np.roll(a, -17), b) - np.roll(xab, -17))) <= 1e-12 * scale
+    xba = eng.xcor(b, a)
+    assert np.max(np.abs(xab - np.conj(np.roll(xba[::-1], 1)))) <= 1e-12 * scale
+    assert np.max(np.abs(eng.xcor(a + 2.5 * c, b) - (xab + 2.5 * eng.xcor(c, b)))) <= 1e-11 * scale
+
+
+# ---------------------------------------------------------------- edge cases --
+def test_edge_cases(eng, oracle):
+    import caf_cookoff_amd as caf
+    # all-zero inputs: every row (0, 0.0), find_peak == (0.0, 0)  (mod.rs:32-35,143)
+    for n in (8, 4096):
+        z = np.zeros(n, dtype=np.complex128)
+        fr = np.array([5.0, 6.0, 7.0])
+        surf, ridx, rval, peak = eng.surface_arrays(z, z, fr, FS)
+        assert not surf.any() and not ridx.any() and not rval.any()
+        assert (peak.freq, peak.idx, peak.val, peak.row) == (0.0, 0, 0.0, -1)
+        rows = eng.caf_surface(z, z, fr, FS)
+        assert eng.find_peak(rows) == (0.0, 0)
+    # empty frequency list: empty surface, peak (0.0, 0)
+    a = np.ones(4096, dtype=np.complex128)
+    surf, ridx, rval, peak = eng.surface_arrays(a, a, np.array([]), FS)
+    assert surf.shape == (0, 8192) and len(ridx) == 0 and (peak.freq, peak.idx) == (0.0, 0)
+    assert eng.find_peak([]) == (0.0, 0)
+    # length mismatch asserts like xcor_rustfft.rs:54-55
+    with pytest.raises(AssertionError):
+        eng.caf_surface(a, a[:2048], [0.0], FS)
+    # non power of two -> CAF_ERR_LENGTH
+    with pytest.raises(caf.CafError) as ei:
+        eng.caf_surface(a[:12], a[:12], [0.0], FS)
+    assert ei.value.code == 2
+    with pytest.raises(caf.CafError):
+        eng.xcor(a[:12], a[:12])
+    # exact ties between rows: the FIRST row wins (mod.rs:36 strict '>')
+    nd, hs = _pair(oracle, 1)
+    fr = np.array([36.0, 36.0, 35.0, 36.0])
+    surf, ridx, rval, peak = eng.surface_arrays(nd, hs, fr, FS)
+    assert rval[0] == rval[1] == rval[3] and peak.row == 0
+    # a delta needle: row peak index is the delay, ties inside a row pick the first lag
+    d = np.zeros(4096, dtype=np.complex128)
+    d[0] = 1.0
+    h = np.zeros(4096, dtype=np.complex128)
+    h[100] = 2.0
+    h[300] = 2.0  # two (nearly) equal peaks: the row argmax is the FIRST maximum of the stored row
+    surf, ridx, rval, peak = eng.surface_arrays(d, h, np.array([0.0]), FS)
+    assert int(ridx[0]) in (100, 300) and int(ridx[0]) == int(np.argmax(surf[0])) and abs(rval[0] - 4.0) < 1e-12
+
+
+def test_negative_lag_and_wraparound(eng, oracle):
+    """index >= n means negative lag (circular): needle delayed w.r.t. haystack."""
+    rng = np.random.default_rng(11)
+    n = 4096
+    a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    a[-64:] = 0
+    nd = np.roll(a, 40)     # needle is the delayed one -> lag -40 -> index 8192-40
+    surf, ridx, rval, peak = eng.surface_arrays(nd, a, np.array([0.0]), FS)
+    assert int(ridx[0]) == 8192 - 40
+    osurf, oidx, _ = oracle.np_caf_surface(nd, a, np.array([0.0]), FS)
+    assert int(oidx[0]) == 8192 - 40 and np.max(np.abs(surf - osurf)) <= TOL64 * osurf.max()
+
+
+# ------------------------------------------------------------------- c64 ------
+def test_c64_fused_bench_config(eng, oracle, golden, manifest):
+    """BASELINE configs[2]: complex64 / f32 surface, tolerance 1e-3 of max; chirp_4
+    (row margin 9.2e-4) must also reproduce the row, chirp_0 (margin 6.8e-6) tau."""
+    fr = oracle.bench_shifts()
+    for k in ("4", "0"):
+        m = manifest["bench"][k]
+        nd, hs = oracle.load_pair(DATA, m["needle"], m["haystack"])
+        surf, ridx, rval, peak = eng.surface_arrays(nd, hs, fr, FS, dtype="c64")
+        assert surf.dtype == np.float32
+        tol = TOL32 * m["surface_max"]
+        assert np.max(np.abs(surf[manifest["full_rows"]].astype(np.float64) - golden[f"bench{k}_rows"])) <= tol
+        assert np.max(np.abs(rval.astype(np.float64) - golden[f"bench{k}_row_val"])) <= tol
+        assert peak.idx == m["best_idx"]
+        assert abs(peak.val - m["peak"]) <= tol
+        err = np.max(np.abs(surf[manifest["full_rows"]].astype(np.float64) - golden[f"bench{k}_rows"])) / m["surface_max"]
+        print(f"c64 chirp_{k}: max|d|/max = {err:.3e}, peak row {peak.row} ({peak.freq} Hz)")
+        if k == "4":
+            assert peak.freq == m["best_freq"]
+
+
+@pytest.mark.parametrize("n", [8, 256, 2048])
+def test_c64_generic_sizes(n, eng, oracle):
+    rng = np.random.default_rng(100 + n)
+    a = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    b = (np.roll(a, n // 4) * np.exp(2j * np.pi * 50.0 * np.arange(n) / FS)).astype(np.complex64)
+    fr = np.array([0.0, 50.0, 100.0])
+    surf, ridx, rval, peak = eng.surface_arrays(a, b, fr, FS, dtype="c64")
+    osurf, oidx, oval = oracle.np_caf_surface(a.astype(np.complex128), b.astype(np.complex128), fr, FS)
+    assert np.max(np.abs(surf - osurf)) <= TOL32 * osurf.max()
+    assert int(ridx[1]) == int(oidx[1]) and peak.row == 1
+
+
+# ------------------------------------------------------- device-resident path --
+def test_plan_batch_and_shards(eng, oracle, golden, manifest):
+    """caf_surface_dev: a batch of two different pairs, and the 2-way row shard
+    used for multi-GPU, reproduce the single-call result (torch only as allocator)."""
+    import torch
+    import caf_cookoff_amd as caf
+    fr = oracle.bench_shifts()
+    pairs = [_pair(oracle, 0), _pair(oracle, 4)]
+    nd = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    hs = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        full = eng.plan(4096, fr, FS)
+        assert full.path == "fused4096" and full.rows == 400
+        surf = torch.empty((2, 400, 8192), dtype=torch.float64, device="cuda")
+        ridx = torch.empty((2, 400), dtype=torch.int64, device="cuda")
+        rval = torch.empty((2, 400), dtype=torch.float64, device="cuda")
+        peak = torch.empty((2, 4), dtype=torch.float64, device="cuda")  # 32-byte caf_peak records
+        full.surface_dev(nd.data_ptr(), hs.data_ptr(), 2, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(),
+                         peak.data_ptr())
+        torch.cuda.synchronize()
+        for b, k in enumerate(("0", "4")):
+            m = manifest["bench"][k]
+            assert np.array_equal(ridx[b].cpu().numpy().astype(np.uint64), golden[f"bench{k}_row_idx"])
+            assert np.max(np.abs(surf[b].cpu().numpy()[manifest["full_rows"]] - golden[f"bench{k}_rows"])) \
+                <= TOL64 * m["surface_max"]
+            pk = np.frombuffer(peak[b].cpu().numpy().tobytes(), dtype=[("val", "<f8"), ("freq", "<f8"),
+                                                                        ("idx", "<u8"), ("row", "<i8")])[0]
+            assert (pk["freq"], pk["idx"]) == (m["best_freq"], m["best_idx"])
+        # 2-way shard of the freq list (what rank 0 / rank 1 of a 2-GPU job run)
+        vals, keys = [], []
+        for rank in range(2):
+            lo, hi = caf.shard_range(400, rank, 2)
+            sh = eng.plan(4096, fr, FS, row_begin=lo, row_end=hi)
+            assert sh.rows == hi - lo
+            r_i = torch.empty((1, sh.rows), dtype=torch.int64, device="cuda")
+            r_v = torch.empty((1, sh.rows), dtype=torch.float64, device="cuda")
+            pk_t = torch.empty((1, 4), dtype=torch.float64, device="cuda")
+            sh.surface_dev(nd[0].data_ptr(), hs[0].data_ptr(), 1, None, r_i.data_ptr(), r_v.data_ptr(),
+                           pk_t.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(r_v[0], rval[0, lo:hi]) and torch.equal(r_i[0], ridx[0, lo:hi])
+            pk = np.frombuffer(pk_t[0].cpu().numpy().tobytes(), dtype=[("val", "<f8"), ("freq", "<f8"),
+                                                                       ("idx", "<u8"), ("row", "<i8")])[0]
+            vals.append(float(pk["val"]))
+            keys.append((int(pk["row"]), int(pk["idx"]), float(pk["freq"])))
+            sh.close()
+        best = max(vals)
+        row, idx, freq = min(k for v, k in zip(vals, keys) if v == best)
+        assert (freq, idx) == (69.0, 202) and row == 338
+        full.close()
+    finally:
+        torch.cuda.synchronize()
+        eng.set_stream(None)

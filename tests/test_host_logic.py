@@ -1,0 +1,67 @@
+"""Host-side logic of the package that needs no GPU: shift lists, file format,
+shard ranges, interface error behaviour."""
+import numpy as np
+import pytest
+
+from conftest import DATA
+
+
+def test_gen_float_shifts_matches_reference_semantics(oracle):
+    import caf_cookoff_amd as caf
+    for args in [(-100.0, 100.0, 0.25), (-50.0, 50.0, 1.0), (30.0, 35.0, 0.05), (80.0, 100.0, 0.1),
+                 (-100.0, 100.0, 0.5)]:
+        a = caf.gen_float_shifts(*args)
+        assert np.array_equal(a, oracle.gen_float_shifts(*args))
+    fr = caf.gen_float_shifts(-100.0, 100.0, 0.25)
+    assert len(fr) == 800 and 69.25 in fr and fr[-1] == 99.75
+    assert np.array_equal(caf.bench_shifts(), oracle.bench_shifts())
+    with pytest.raises(ValueError):
+        caf.gen_float_shifts(0.0, 1.0, 0.0001)  # step_by(0) panics in the reference
+
+
+def test_read_file_c64(oracle, tmp_path):
+    import caf_cookoff_amd as caf
+    p = DATA / "chirp_0_raw.c64"
+    a = caf.read_file_c64(p)
+    assert a.dtype == np.complex128 and len(a) == 4096
+    assert np.array_equal(a, oracle.read_file_c64(p))
+    raw = np.fromfile(p, dtype="<f4")
+    assert a[5].real == float(raw[10]) and a[5].imag == float(raw[11])  # widened, not re-rounded
+    assert caf.read_file_c64_f32(p).dtype == np.complex64
+    # utils.rs:45-62 writer is numpy complex128 compatible
+    out = tmp_path / "x.bin"
+    caf.write_file_binary(a[:7], out)
+    assert np.array_equal(np.fromfile(out, dtype=np.complex128), a[:7])
+    bad = tmp_path / "bad.c64"
+    bad.write_bytes(b"\0" * 12)
+    with pytest.raises(ValueError):
+        caf.read_file_c64(bad)
+
+
+def test_load_files_truncates_and_pads(tmp_path):
+    import caf_cookoff_amd as caf
+    nd, hs = caf.load_files(DATA / "chirp_0_raw.c64", DATA / "chirp_0_T+202samp_F+69.25Hz.c64")
+    assert len(nd) == len(hs) == 4096
+    short = tmp_path / "s.c64"
+    np.arange(8, dtype="<f4").tofile(short)  # 4 samples
+    nd2, hs2 = caf.load_files(DATA / "chirp_0_raw.c64", short)
+    assert len(hs2) == 4096 and hs2[3] == 6 + 7j and not hs2[4:].any()
+
+
+@pytest.mark.parametrize("nfreq,world", [(400, 1), (400, 2), (400, 8), (4096, 8), (7, 3), (3, 8)])
+def test_shard_range_partitions(nfreq, world):
+    import caf_cookoff_amd as caf
+    spans = [caf.shard_range(nfreq, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == nfreq
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 == b0 and a0 <= a1
+    sizes = [b - a for a, b in spans]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_xcor_interface_errors():
+    import caf_cookoff_amd as caf
+    with pytest.raises(caf.CafError):
+        caf.Xcor(12)  # not a power of two
+    with pytest.raises(caf.CafError):
+        caf.Xcor(0)
