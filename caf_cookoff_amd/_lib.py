@@ -74,6 +74,32 @@ SYMBOLS = [
 _lib = None
 
 
+def _prefer_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1
+    (same SONAMEs as /opt/rocm).  Two HSA runtimes in one process cannot both own the
+    GPU, so when torch is installed bind to ITS runtime before libcaf_hip.so pulls in
+    the system one; torch imported later then finds its own libraries already loaded.
+    The library needs only hip_4.2/6.0-versioned symbols, present in both."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("CAF_HIP_SYSTEM_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return
+    libdir = Path(spec.origin).parent / "lib"
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = libdir / name
+        if p.exists():
+            try:
+                ctypes.CDLL(str(p), mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load() -> ctypes.CDLL:
     """Load libcaf_hip.so and bind every declared symbol; raise if absent."""
     global _lib
@@ -85,6 +111,7 @@ def load() -> ctypes.CDLL:
             f"{path} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C caf_cookoff_amd/csrc). "
             "caf_cookoff_amd has no CPU fallback.")
+    _prefer_torch_hip_runtime()
     lib = ctypes.CDLL(str(path))
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
