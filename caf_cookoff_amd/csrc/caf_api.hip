@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -13,6 +14,7 @@
 
 #include "../../include/caf_hip.h"
 #include "kernels_fused4096.hpp"
+#include "kernels_seq4096.hpp"
 #include "kernels_generic.hpp"
 
 using namespace caf;
@@ -87,11 +89,13 @@ struct caf_plan {
     double *d_freqs = nullptr;  // this shard's slice
     double *d_ph = nullptr;
     // fused
-    void *d_base = nullptr, *d_step = nullptr;
+    void *d_phasor = nullptr;
     DevBuf spec;
     // generic
     void *d_tw = nullptr;  // borrowed from ctx cache
     DevBuf wx, wy, hx, hy;
+    unsigned long long *dbg = nullptr;  // diagnostic stamps buffer (caf_debug_set_stamps)
+    int variant = 0;                    // 0: sequential-chain row kernel, 1: 512-thread lane-half kernel
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -312,11 +316,10 @@ static int plan_build_tables(caf_plan *p)
     if (p->fused) {
         if ((rc = build_fused_tables<T>(c, dt))) return rc;
         const size_t nr = p->rows + 1;  // +1: the f = 0 row for the haystack transform
-        HIPCHK(hipMalloc(&p->d_base, nr * 512 * sizeof(cpx<T>)));
-        HIPCHK(hipMalloc(&p->d_step, nr * 32 * sizeof(cpx<T>)));
-        const size_t threads = nr * 512;
+        HIPCHK(hipMalloc(&p->d_phasor, nr * 64 * sizeof(cpx<T>)));
+        const size_t threads = nr * 64;
         k_fused_phasors<T><<<(unsigned)((threads + 255) / 256), 256, 0, c->stream>>>(
-            p->d_ph, (int)p->rows, (cpx<T> *)p->d_base, (cpx<T> *)p->d_step);
+            p->d_ph, (int)p->rows, (cpx<T> *)p->d_phasor);
         KCHK();
     } else {
         if ((rc = get_generic_tw<T>(c, p->L, dt, &p->d_tw))) return rc;
@@ -348,6 +351,7 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     p->row_begin = row_begin;
     p->rows = row_end - row_begin;
     p->fused = (n == (size_t)F_N);
+    if (const char *ev = getenv("CAF_ROW_KERNEL")) p->variant = atoi(ev);
     int rc = CAF_OK;
     auto bail = [&](int code) { caf_plan_destroy(p); return code; };
     if (p->rows) {
@@ -378,8 +382,7 @@ extern "C" int caf_plan_destroy(caf_plan *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->d_freqs) (void)hipFree(p->d_freqs);
     if (p->d_ph) (void)hipFree(p->d_ph);
-    if (p->d_base) (void)hipFree(p->d_base);
-    if (p->d_step) (void)hipFree(p->d_step);
+    if (p->d_phasor) (void)hipFree(p->d_phasor);
     p->spec.release(); p->wx.release(); p->wy.release(); p->hx.release(); p->hy.release();
     for (auto ev : p->ev) (void)hipEventDestroy(ev);
     if (p->ctx->cached == p) p->ctx->cached = nullptr;
@@ -428,6 +431,23 @@ extern "C" int caf_plan_timing_end(caf_plan *p, double *ms_total, uint64_t *laun
     return CAF_OK;
 }
 
+// Internal (not in include/caf_hip.h): route the next caf_surface_dev calls of a fused
+// plan through the stamped DIAG instantiation; d_buf = 32*8*F_NSTAMP u64 or NULL to stop.
+extern "C" int caf_debug_set_stamps(caf_plan *p, void *d_buf)
+{
+    if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
+    p->dbg = (unsigned long long *)d_buf;
+    return CAF_OK;
+}
+
+// Internal: choose the row-kernel variant of a fused plan (0 sequential-chain, 1 lane-half).
+extern "C" int caf_debug_set_variant(caf_plan *p, int variant)
+{
+    if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
+    p->variant = variant;
+    return CAF_OK;
+}
+
 // ------------------------------------------------------------ surface (dev) --
 template <typename T>
 static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch,
@@ -437,18 +457,19 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     int rc;
     if ((rc = p->spec.ensure(batch * 2 * 16 * 256 * sizeof(cpx<T>)))) return rc;
     FusedArgs<T> a;
-    a.ph_base = (const cpx<T> *)p->d_base;
-    a.ph_step = (const cpx<T> *)p->d_step;
+    a.phasor = (const cpx<T> *)p->d_phasor;
     a.tab.tw4096 = (const cpx<T> *)c->tw4096[p->dtype];
     a.tab.th = (const cpx<T> *)c->th[p->dtype];
     a.spec = (cpx<T> *)p->spec.p;
     a.rows = (int)p->rows;
     a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr;
+    a.dbg = p->dbg;
     // haystack spectrum, once per surface (the reference recomputes it per row,
     // xcor_rustfft.rs:58-59)
     a.sig = (const cpx<T> *)d_hay;
     a.total = (int)batch;
-    k_fused_rows<T, true><<<(unsigned)batch, F_THREADS, 0, c->stream>>>(a);
+    k_fused_prepare<T><<<(unsigned)(batch < (size_t)c->cu_count ? batch : (size_t)c->cu_count), F_THREADS, 0,
+                         c->stream>>>(a);
     KCHK();
     const size_t total = batch * p->rows;
     if (total == 0) return CAF_OK;
@@ -457,11 +478,33 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     a.surface = (T *)d_surface;
     a.row_idx = d_ridx;
     a.row_val = (T *)d_rval;
-    const size_t per_cu = fused_lds_bytes<T>() * 2 <= 160 * 1024 ? 2 : 1;
-    const size_t cap = (size_t)c->cu_count * per_cu;
-    const unsigned grid = (unsigned)(total < cap ? total : cap);
     if ((rc = timing_mark(p))) return rc;
-    k_fused_rows<T, false><<<grid, F_THREADS, 0, c->stream>>>(a);
+    if (p->variant == 0 && !p->dbg) {
+        size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
+        if (per_cu > 2) per_cu = 2;  // 256 VGPRs/wave cap the kernel at 2 waves per SIMD
+        static const int wg_per_cu_env = getenv("CAF_WG_PER_CU") ? atoi(getenv("CAF_WG_PER_CU")) : 0;  // measurement only
+        if (wg_per_cu_env > 0) per_cu = (size_t)wg_per_cu_env;
+        const size_t cap = (size_t)c->cu_count * per_cu;
+        const unsigned grid = (unsigned)(total < cap ? total : cap);
+        static const int store_mode = getenv("CAF_STORE_MODE") ? atoi(getenv("CAF_STORE_MODE")) : 0;
+        switch (store_mode) {  // 1-3: measurement variants only
+        case 1: k_seq_rows<T, 1><<<grid, S_THREADS, 0, c->stream>>>(a); break;
+        case 2: k_seq_rows<T, 2><<<grid, S_THREADS, 0, c->stream>>>(a); break;
+        case 3: k_seq_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a); break;
+        case 11: k_seq_rows<T, 0, 1><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // no LDS
+        case 12: k_seq_rows<T, 0, 2><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // no global loads
+        case 13: k_seq_rows<T, 3, 3><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // VALU only
+        default: k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;
+        }
+    } else {
+        const size_t per_cu = fused_lds_bytes<T>() * 2 <= 160 * 1024 ? 2 : 1;
+        const size_t cap = (size_t)c->cu_count * per_cu;
+        const unsigned grid = (unsigned)(total < cap ? total : cap);
+        if (p->dbg)
+            k_fused_rows<T, true><<<grid, F_THREADS, 0, c->stream>>>(a);
+        else
+            k_fused_rows<T, false><<<grid, F_THREADS, 0, c->stream>>>(a);
+    }
     KCHK();
     if ((rc = timing_mark(p))) return rc;
     return CAF_OK;

@@ -87,4 +87,41 @@ __device__ __forceinline__ void wave_arg_reduce(T &bv, uint32_t &bi)
     }
 }
 
+// DPP flavour of the same reduction (no LDS-pipe traffic): afterwards lane 63 holds the
+// wave's (max value, lowest index among equals); other lanes hold partial results.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_t(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL, ROW_MASK>((int)b), hi = dpp_i<CTRL, ROW_MASK>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_t(float v)
+{
+    return __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(v)));
+}
+template <typename T, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void arg_step(T &bv, uint32_t &bi)
+{
+    const T ov = dpp_t<CTRL, ROW_MASK>(bv);
+    const uint32_t oi = (uint32_t)dpp_i<CTRL, ROW_MASK>((int)bi);
+    arg_merge(bv, bi, ov, oi);  // lanes not written by the DPP keep (bv, bi): merge with self
+}
+template <typename T>
+__device__ __forceinline__ void wave_arg_reduce_dpp(T &bv, uint32_t &bi)
+{
+    arg_step<T, 0xB1, 0xF>(bv, bi);   // quad_perm [1,0,3,2]
+    arg_step<T, 0x4E, 0xF>(bv, bi);   // quad_perm [2,3,0,1]
+    arg_step<T, 0x141, 0xF>(bv, bi);  // row_half_mirror
+    arg_step<T, 0x140, 0xF>(bv, bi);  // row_mirror      -> every lane of a 16-row holds the row result
+    arg_step<T, 0x142, 0xA>(bv, bi);  // row_bcast15 into rows 1,3
+    arg_step<T, 0x143, 0xC>(bv, bi);  // row_bcast31 into rows 2,3 -> lane 63 has the wave result
+}
+
 }  // namespace caf

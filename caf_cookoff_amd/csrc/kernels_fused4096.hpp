@@ -25,7 +25,7 @@
 //   * |.|^2, the first-max argmax (mod.rs:143-151) and the coalesced surface store
 //     are the epilogue of the last butterfly.
 //
-// LDS: (2 chains x 4096 + 256) x sizeof(complex) + 256 B = 132.25 KiB (f64) / 66.25 KiB (f32).
+// LDS: (2 chains x 4352 (padded) + 256) x sizeof(complex) + 256 B = 140.25 KiB (f64) / 70.25 KiB (f32).
 // Barriers: 3 per row.  HBM traffic per row: the 2n-real output row once; inputs,
 // spectrum and phasor tables are L2-resident.
 #pragma once
@@ -55,33 +55,27 @@ __global__ void k_fused_tables(cpx<T> *__restrict__ tw4096, cpx<T> *__restrict__
     if (i < 256) th[i] = cispi_f64<T>(2.0 * (double)i / 8192.0);
 }
 
-// Per-row phasor tables of a plan (one thread per (row, chain, t)):
-//   base[row][c][t] = e^{j*ph*t}        * (c ? e^{-2*pi*i*t/8192}       : 1),  t < 256
-//   step[row][c][q] = e^{j*ph*256*q}    * (c ? e^{-2*pi*i*256*q/8192}   : 1),  q < 16
-// so that needle[t+256q]*base*step = needle[n]*w^n*(c ? conj(T^n) : 1) and the chain
-// input is its conjugate.  Row `nrows` (one past the end) is the f = 0 row used to
-// transform the haystack.
+// Per-row phasor table of a plan: 64 entries per row (1 KiB f64),
+//   [ 0..15] lo[j]    = e^{j*ph*j}
+//   [16..31] hi[j]    = e^{j*ph*16*j}
+//   [32..47] step0[q] = e^{j*ph*256*q}
+//   [48..63] step1[q] = e^{j*ph*256*q} * e^{-2*pi*i*256*q/8192}      (odd chain)
+// needle[t+256q]*lo[t&15]*hi[t>>4]*step_c[q]*(c ? e^{-2*pi*i*t/8192} : 1) is the mixer
+// output (mod.rs:46-65) times the odd chain's half-bin rotation; the chain input is its
+// conjugate.  Row `nrows` (one past the end) is the f = 0 row used to transform the
+// haystack.  Every entry comes from one f64 sincos of the exact phase product.
 template <typename T>
-__global__ void k_fused_phasors(const double *__restrict__ ph, int nrows,
-                                cpx<T> *__restrict__ base, cpx<T> *__restrict__ step)
+__global__ void k_fused_phasors(const double *__restrict__ ph, int nrows, cpx<T> *__restrict__ tab)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = g / 512, rem = g % 512, c = rem / 256, t = rem % 256;
+    const int row = g >> 6, e = g & 63, j = e & 15, kind = e >> 4;
     if (row > nrows) return;
     const double p = row < nrows ? ph[row] : 0.0;
-    {
-        double s, co, s2, c2;
-        sincos(p * (double)t, &s, &co);
-        sincospi(c ? -2.0 * (double)t / 8192.0 : 0.0, &s2, &c2);
-        base[(size_t)row * 512 + c * 256 + t] = {(T)(co * c2 - s * s2), (T)(co * s2 + s * c2)};
-    }
-    if (t < 16) {
-        const int q = t;
-        double s, co, s2, c2;
-        sincos(p * (double)(256 * q), &s, &co);
-        sincospi(c ? -2.0 * (double)(256 * q) / 8192.0 : 0.0, &s2, &c2);
-        step[(size_t)row * 32 + c * 16 + q] = {(T)(co * c2 - s * s2), (T)(co * s2 + s * c2)};
-    }
+    const double mult = kind == 0 ? 1.0 : kind == 1 ? 16.0 : 256.0;
+    double s, co, s2 = 0.0, c2 = 1.0;
+    sincos(p * (mult * (double)j), &s, &co);
+    if (kind == 3) sincospi(-2.0 * (double)(256 * j) / 8192.0, &s2, &c2);
+    tab[(size_t)row * 64 + e] = {(T)(co * c2 - s * s2), (T)(co * s2 + s * c2)};
 }
 
 // ---- radix-16 butterfly, positive exponent, natural-order in and out -----------
@@ -137,6 +131,36 @@ __device__ __forceinline__ void dft16(cpx<T> (&v)[16])
     swp(v[6], v[9]); swp(v[7], v[13]); swp(v[11], v[14]);
 }
 
+// dft16 whose outputs are handed to `sink(k, X[k])` as soon as each radix-4 group of the
+// second stage retires, with a scheduling fence per group: the caller's twiddle multiply +
+// ds_write of four outputs then sits between butterfly groups instead of all sixteen
+// ds_write_b128 piling up behind the math (four waves doing that at once queue 64 stores on
+// the CU's LDS store path and stall in-order issue; SQ_WAIT_INST_LDS in profiles/r01_v2).
+template <typename T, typename F>
+__device__ __forceinline__ void dft16_sink(cpx<T> (&v)[16], F &&sink)
+{
+    const T c1 = T(0.92387953251128675612818318939679);
+    const T s1 = T(0.38268343236508977172845998403040);
+#pragma unroll
+    for (int q0 = 0; q0 < 4; ++q0) dft4(v[q0], v[q0 + 4], v[q0 + 8], v[q0 + 12]);
+    v[5] = cmul(v[5], cpx<T>{c1, s1});
+    v[9] = mul_w8(v[9]);
+    v[13] = cmul(v[13], cpx<T>{s1, c1});
+    v[6] = mul_w8(v[6]);
+    v[10] = muli(v[10]);
+    v[14] = mul_w8_3(v[14]);
+    v[7] = cmul(v[7], cpx<T>{s1, c1});
+    v[11] = mul_w8_3(v[11]);
+    v[15] = cmul(v[15], cpx<T>{-c1, -s1});
+#pragma unroll
+    for (int r0 = 0; r0 < 4; ++r0) {
+        dft4(v[4 * r0], v[4 * r0 + 1], v[4 * r0 + 2], v[4 * r0 + 3]);  // X[r0 + 4*r1] at v[4*r0 + r1]
+#pragma unroll
+        for (int r1 = 0; r1 < 4; ++r1) sink(r0 + 4 * r1, v[4 * r0 + r1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Orders this wave's LDS accesses without a workgroup barrier: LDS operations of
 // one wave execute in issue order, so a compiler-level fence is all that is needed
 // for the wave-local exchanges (the 256-element block a wave owns is read and
@@ -190,164 +214,403 @@ __device__ constexpr double W32_SIN[8] = {0.0, 0.1950903220161282678482848684770
 
 template <typename T>
 struct FusedArgs {
-    const cpx<T> *sig;      // PREPARE: haystack [batch][4096]; else needle [batch][4096]
-    cpx<T> *spec;           // Hs [batch][2][16][256]: PREPARE writes, else reads
-    const cpx<T> *ph_base;  // [rows+1][2][256]
-    const cpx<T> *ph_step;  // [rows+1][2][16]
+    const cpx<T> *sig;      // prepare: haystack [batch][4096]; rows: needle [batch][4096]
+    cpx<T> *spec;           // Hs [batch][2][16][256]: prepare writes, rows read
+    const cpx<T> *phasor;   // [rows+1][64]  (k_fused_phasors)
     FusedTables<T> tab;
     T *surface;             // [batch][rows][8192] or nullptr
     uint64_t *row_idx;      // [batch][rows]
     T *row_val;             // [batch][rows]
     int rows;               // rows per surface handled by this plan
-    int total;              // batch*rows (PREPARE: batch)
+    int total;              // batch*rows (prepare: batch)
+    unsigned long long *dbg;  // DIAG builds only: [iter][wave][F_NSTAMP] s_memtime stamps of workgroup 0
 };
 
-// LDS bytes: 2 chains x 4096 complex + 256-entry W_256 table + argmax scratch
-template <typename T>
-constexpr size_t fused_lds_bytes() { return (2 * 4096 + 256) * sizeof(cpx<T>) + 256; }
+constexpr int F_NSTAMP = 17;
+// In-kernel stamp (cdna_hip_programming.md section 7): s_memtime + lgkmcnt(0) in ONE asm
+// statement, fenced by sched_barriers.  Only the DIAG instantiation executes any.
+#define CAF_STAMP(i)                                                                        \
+    if constexpr (DIAG) {                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[i])::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    }
 
-template <typename T, bool PREPARE>
-__global__ __launch_bounds__(F_THREADS) void k_fused_rows(const FusedArgs<T> A)
+// LDS geometry.  One chain = 16 blocks (one per high digit) of 256 elements, element j of
+// a block stored at j + (j >> 4): one pad element per 16.  Every exchange pattern is then
+// "one per-thread base + a compile-time offset" (ds_* 16-bit immediates, 3 base VGPRs in
+// all) and every wave-level access is bank-conflict-free:
+//   pattern A (by column):  pos(k, t)            = k*272 + t + (t>>4)          offset k*272
+//   pattern B (gather n1):  pos(hi4, 16*k + lo4) = hi4*272 + lo4 + 17*k        offset k*17
+//   pattern C (transposed): pos(hi4, 16*lo4 + k) = hi4*272 + 17*lo4 + k        offset k
+constexpr int F_BLK = 272;             // padded block stride (elements)
+constexpr int F_CHAIN = 16 * F_BLK;    // 4352 elements per chain
+// LDS bytes: 2 padded chains + 256-entry W_256 table + argmax scratch
+template <typename T>
+constexpr size_t fused_lds_bytes() { return (2 * F_CHAIN + 256) * sizeof(cpx<T>) + 256; }
+
+// Per-thread geometry shared by the prepare and the row kernel.
+struct FusedLane {
+    int tid, lane, wave, chain, t, hi4, lo4;
+    int pA, pB, pC;  // LDS element offsets of the three access patterns (within the chain)
+    __device__ __forceinline__ FusedLane()
+    {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        wave = tid >> 6;
+        chain = lane >> 5;             // 0: even bins (E), 1: odd bins (O)
+        t = wave * 32 + (lane & 31);   // butterfly column 0..255
+        hi4 = t >> 4;
+        lo4 = t & 15;
+        pA = t + hi4;
+        pB = hi4 * F_BLK + lo4;
+        pC = hi4 * F_BLK + 17 * lo4;
+    }
+};
+
+// Forward (DIF) chain after the mixer: v[q] = u[t + 256q]  ->  v[k2] = G[k0 + 16*k1 + 256*k2]
+// with (k0,k1) = (hi4, lo4).  One workgroup barrier (exchange 1); exchange 2 is wave-local.
+template <typename T>
+__device__ __forceinline__ void fwd_chain(cpx<T> (&v)[16], const cpx<T> (&twA)[16], const cpx<T> *twB,
+                                          cpx<T> *Lc, const FusedLane &L)
+{
+    // pass 1: over n2, twiddle W_4096^(t*k0)
+    dft16(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twA[k]);
+    // exchange 1: [k0][t]  ->  thread (k0'=hi4, n0'=lo4) gathers over n1
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Lc[L.pA + k * F_BLK] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
+    // pass 2: over n1, twiddle W_256^(n0'*k1)
+    dft16(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twB[16 * k]);
+    // exchange 2 (wave-local): write [k0'][k1][n0'], read transposed
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Lc[L.pB + 17 * k] = v[k];
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = Lc[L.pC + k];
+    // pass 3: over n0
+    dft16(v);
+}
+
+// mixer (mod.rs:46-65) + conjugation: v[q] = conj(a[q] * pb * ps[q])
+template <typename T>
+__device__ __forceinline__ cpx<T> row_phasor_base(const cpx<T> *ph, const FusedLane &L, cpx<T> cfac)
+{
+    return cmul(cmul(ph[L.lo4], ph[16 + L.hi4]), cfac);
+}
+
+// ---- haystack spectrum (once per surface; the reference recomputes it per row) -----
+// Hs = FFT_8192(haystack ++ 0)/8192 = conj(IDFT(conj h))/L, stored in the register layout
+// of the row kernel: spec[chain][k2][t].
+template <typename T>
+__global__ __launch_bounds__(F_THREADS) void k_fused_prepare(const FusedArgs<T> A)
 {
     using C = cpx<T>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[fused_lds_bytes<T>()];
     C *const lds = reinterpret_cast<C *>(smem);
-    C *const twb = lds + 2 * 4096;  // twb[k*16 + lo] = W_256^(lo*k)
-    unsigned char *const scratch = smem + (2 * 4096 + 256) * sizeof(C);
+    C *const twb = lds + 2 * F_CHAIN;
+    const FusedLane L;
+    C *const Lc = lds + L.chain * F_CHAIN;
+    C twA[16];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) twA[k] = A.tab.tw4096[L.t * k];
+    if (L.tid < 256) twb[L.tid] = A.tab.tw4096[16 * (L.tid & 15) * (L.tid >> 4)];
+    __syncthreads();
+    const C *const twB = twb + L.lo4;
+    const C th = A.tab.th[L.t];
+    const C cfac = L.chain ? conj(th) : C{T(1), T(0)};
+    const C *ph = A.phasor + (size_t)A.rows * 64;  // the f = 0 row
+    for (int b = blockIdx.x; b < A.total; b += gridDim.x) {
+        const C *sig = A.sig + (size_t)b * F_N;
+        const C pb = row_phasor_base(ph, L, cfac);
+        const C *ps = ph + 32 + L.chain * 16;
+        C v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = conj(cmul(cmul(sig[L.t + 256 * q], pb), ps[q]));
+        fwd_chain(v, twA, twB, Lc, L);
+        C *spec = A.spec + (size_t)b * (2 * 16 * 256) + L.chain * (16 * 256);
+        const T inv = T(1.0 / 8192.0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) spec[k * 256 + L.t] = {v[k].x * inv, -v[k].y * inv};
+        __syncthreads();  // next iteration's exchange-1 writes vs this one's reads
+    }
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int chain = lane >> 5;              // 0: even bins (E), 1: odd bins (O)
-    const int t = wave * 32 + (lane & 31);    // butterfly column 0..255
-    const int hi4 = t >> 4, lo4 = t & 15;
-    C *const Lc = lds + chain * 4096;
+// ---- surface store: 16 bytes per lane, write-through ------------------------------------
+// Adjacent lanes own adjacent lags; a quad_perm DPP swap gives every lane two consecutive
+// lags of one register row, so a row leaves as 16-B-per-lane `sc1` stores: they go straight
+// through L2 without keeping the line, which would otherwise evict the L2-resident inputs
+// (needle, haystack spectrum, phasors) that every row re-reads (MI355X_MICROARCH.md, store
+// flavours).
+template <typename T>
+__device__ __forceinline__ T dpp_xor1(T v);
+template <>
+__device__ __forceinline__ double dpp_xor1<double>(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <>
+__device__ __forceinline__ float dpp_xor1<float>(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
 
-    // ---- register-resident twiddles --------------------------------------------
+typedef unsigned caf_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned caf_v2u __attribute__((ext_vector_type(2)));
+constexpr int CAF_AUX_SC1 = 16;  // gfx940+ cache-policy bit 4 = sc1 (write-through, line not kept)
+
+template <int AUX>
+__device__ __forceinline__ void store_pair_aux(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, double x0, double x1)
+{
+    const long long a = __double_as_longlong(x0), b = __double_as_longlong(x1);
+    caf_v4u d = {(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, byte_off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void store_pair_aux(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float x0, float x1)
+{
+    caf_v2u d = {__float_as_uint(x0), __float_as_uint(x1)};
+    __builtin_amdgcn_raw_buffer_store_b64(d, rs, byte_off, 0, AUX);
+}
+template <typename T>
+__device__ __forceinline__ void store_pair_wt(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, T x0, T x1)
+{
+    store_pair_aux<CAF_AUX_SC1>(rs, byte_off, x0, x1);
+}
+
+// 16-B (f64) / 8-B (f32) complex load through a buffer descriptor: per-lane byte offset in a
+// VGPR, the 4096-byte-strided register-row offset in an SGPR -> one address VGPR per table.
+__device__ __forceinline__ cpx<double> bload(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, cpx<double> *)
+{
+    const caf_v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return {__longlong_as_double(((long long)r.y << 32) | r.x), __longlong_as_double(((long long)r.w << 32) | r.z)};
+}
+__device__ __forceinline__ cpx<float> bload(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, cpx<float> *)
+{
+    const caf_v2u r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return {__uint_as_float(r.x), __uint_as_float(r.y)};
+}
+
+// ---- the row kernel ------------------------------------------------------------------------
+template <typename T, bool DIAG = false>
+__global__ __launch_bounds__(F_THREADS) void k_fused_rows(const FusedArgs<T> A)
+{
+    using C = cpx<T>;
+    unsigned long long st[F_NSTAMP] = {};
+    int iter = 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[fused_lds_bytes<T>()];
+    C *const lds = reinterpret_cast<C *>(smem);
+    C *const twb = lds + 2 * F_CHAIN;  // twb[k*16 + lo] = W_256^(lo*k)
+    unsigned char *const scratch = smem + (2 * F_CHAIN + 256) * sizeof(C);
+    const FusedLane L;
+    C *const Lc = lds + L.chain * F_CHAIN;
+
     // ---- twiddles: W_4096^(t*k) in registers, W_256^(lo4*k) in LDS ---------------
     C twA[16];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) twA[k] = A.tab.tw4096[t * k];
-    if (tid < 256) twb[tid] = A.tab.tw4096[16 * (tid & 15) * (tid >> 4)];
-    __syncthreads();
-    const C *const twB = twb + lo4;  // twB[16*k]
-    // last-stage twiddle base: T^(t + 256*m2), lower lanes own m2 = 8+i -> extra *i
-    C tbase = A.tab.th[t];
-    if (chain == 0) tbase = muli(tbase);
+    for (int k = 1; k < 16; ++k) twA[k] = A.tab.tw4096[L.t * k];
+    if (L.tid < 256) twb[L.tid] = A.tab.tw4096[16 * (L.tid & 15) * (L.tid >> 4)];
+    const C *const twB = twb + L.lo4;  // twB[16*k]
+    // last-stage twiddle base T^(t + 256*m2): lanes 0-31 end up owning m2 = 8+i -> extra *i
+    const C th = A.tab.th[L.t];
+    const C tbase = L.chain == 0 ? muli(th) : th;
+    const C cfac = L.chain ? conj(th) : C{T(1), T(0)};  // odd chain: e^{-2*pi*i*t/8192}
+    const int mbase = L.t + (L.chain == 0 ? 2048 : 0);
+    const int mpair = (L.t & ~1) + (L.chain == 0 ? 2048 : 0);
+    const bool odd = L.lane & 1;
 
-    C v[16];
-    int parity = 0;
-    for (int g = blockIdx.x; g < A.total; g += gridDim.x, parity ^= 1) {
-        const int b = PREPARE ? g : g / A.rows;
-        const int r = PREPARE ? A.rows : g % A.rows;  // PREPARE uses the f=0 row
-
-        // ---- mixer (mod.rs:46-65) fused into the first butterfly load -----------
-        {
-            const C *sig = A.sig + (size_t)b * F_N;
-            const C pb = A.ph_base[(size_t)r * 512 + chain * 256 + t];
-            const C *ps = A.ph_step + (size_t)r * 32 + chain * 16;
+    // ---- software pipeline prologue: needle samples of the first row -----------------
+    int g = blockIdx.x;
+    C a[16];
+    const unsigned voff_sig = (unsigned)(L.t * sizeof(C));
+    const unsigned voff_spec = (unsigned)((L.chain * 4096 + L.t) * sizeof(C));
+    {
+        const int gc = g < A.total ? g : A.total - 1;  // total >= 1 (host guarantees)
+        const __amdgpu_buffer_rsrc_t rs_sig =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const C x = sig[t + 256 * q];
-                v[q] = conj(cmul(cmul(x, pb), ps[q]));
-            }
+        for (int q = 0; q < 16; ++q) a[q] = bload(rs_sig, voff_sig, (unsigned)(256 * q * sizeof(C)), (C *)nullptr);
+    }
+    __syncthreads();  // twb table visible
+
+    // (A static s_setprio(1) for waves 4-7 was measured: it only swaps which wave of a SIMD
+    // pair starves -- barrier wait moves from waves 0-3 to waves 4-7, throughput -2 %.)
+    int parity = 0, prev_g = -1;
+    for (; g < A.total; parity ^= 1, ++iter) {
+        CAF_STAMP(0);
+        const int gn = g + gridDim.x;
+        const int b = g / A.rows, r = g - b * A.rows;
+        C v[16];
+        // ---- mixer (mod.rs:46-65) fused into the first butterfly's operands ---------
+        {
+            const C *ph = A.phasor + (size_t)r * 64;
+            const C pb = row_phasor_base(ph, L, cfac);
+            const C *ps = ph + 32 + L.chain * 16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = conj(cmul(cmul(a[q], pb), ps[q]));
         }
-        // ---- forward (DIF) pass 1: over n2, twiddle W_4096^(t*k0) ---------------
+        CAF_STAMP(1);
+        // ---- forward chain -------------------------------------------------------------
         dft16(v);
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twA[k]);
-        // exchange 1: [k0][t]  ->  thread (k0'=hi4, n0'=lo4) gathers over n1
+        CAF_STAMP(2);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) Lc[k * 256 + t] = v[k];
+        for (int k = 0; k < 16; ++k) Lc[L.pA + k * F_BLK] = v[k];
+        CAF_STAMP(3);
         __syncthreads();
+        CAF_STAMP(4);
+        // row result of the previous iteration (its scratch was written before this barrier)
+        if (L.tid == 0 && prev_g >= 0) {
+            const T *sv = reinterpret_cast<const T *>(scratch + (parity ^ 1) * 128);
+            const uint32_t *si = reinterpret_cast<const uint32_t *>(scratch + (parity ^ 1) * 128 + 64);
+            T bv = sv[0];
+            uint32_t bi = si[0];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = Lc[hi4 * 256 + 16 * k + lo4];
-        // ---- pass 2: over n1, twiddle W_256^(n0'*k1) ----------------------------
+            for (int w = 1; w < 8; ++w) arg_merge(bv, bi, sv[w], si[w]);
+            A.row_idx[prev_g] = bi;
+            A.row_val[prev_g] = bv;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
+        CAF_STAMP(5);
         dft16(v);
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twB[16 * k]);
-        // exchange 2 (wave-local, XOR-swizzled): [k0'][k1][n0'^k1]
+        CAF_STAMP(6);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) Lc[hi4 * 256 + k * 16 + (lo4 ^ k)] = v[k];
+        for (int k = 0; k < 16; ++k) Lc[L.pB + 17 * k] = v[k];
         wave_lds_fence();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = Lc[hi4 * 256 + lo4 * 16 + (k ^ lo4)];
-        // ---- pass 3: over n0 -> G[k0 + 16*k1 + 256*k2], k2 = register ----------
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pC + k];
+        CAF_STAMP(7);
+        // haystack-spectrum loads issued here land under the pass-3 butterfly
+        C h[16];
+        {
+            const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(A.spec + (size_t)b * (2 * 16 * 256)), 0, 2 * 16 * 256 * (int)sizeof(C), 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
+        }
+        dft16(v);  // -> G[k0 + 16*k1 + 256*k2], k2 = register
+        CAF_STAMP(8);
+        // ---- spectrum product (xcor_rustfft.rs:64-73) ---------------------------------
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = cmul(v[k], h[k]);
+        // ---- inverse (DIT) pass I: over k2 -> m0 -----------------------------------------
+        dft16(v);
+        CAF_STAMP(9);
+        // exchange 3 (wave-local): thread (k0,k1) writes transposed, thread (k0,m0) gathers k1
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Lc[L.pC + k] = v[k];
+        wave_lds_fence();
+        // twiddle W_256^(k1*m0)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twB[16 * k]);
+        CAF_STAMP(10);
+        // ---- pass II: over k1 -> m1 ------------------------------------------------------
+        dft16(v);
+        // exchange 4: [k0][16*m1 + m0] -> thread j=t gathers over k0
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Lc[L.pB + 17 * k] = v[k];
+        CAF_STAMP(11);
+        __syncthreads();
+        CAF_STAMP(12);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pA + k * F_BLK];
+        CAF_STAMP(13);
+        // All LDS reads of this row are done: release the next row's exchange-1 writes here,
+        // so the epilogue, the stores and the next mixer run barrier-free.
+        __syncthreads();
+        CAF_STAMP(14);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twA[k]);
+        // ---- pass III: over k0 -> y[t + 256*m2], m2 = register ---------------------------
         dft16(v);
 
-        if constexpr (PREPARE) {
-            // Hs = conj(IDFT(conj h)) / L = FFT(h)/L, stored in register layout
-            C *spec = A.spec + (size_t)b * (2 * 16 * 256) + chain * (16 * 256);
-            const T inv = T(1.0 / 8192.0);
+        // ---- last radix-2 stage across the lane halves + epilogue ------------------------
+        // after the swap: lanes 0-31 hold (E,O)[t+256*(8+i)], lanes 32-63 (E,O)[t+256*i].
+        // Register rows are retired two at a time: combine, |.|^2, argmax, 16-B stores; the
+        // freed registers immediately receive the NEXT row's needle samples, which land
+        // under the remaining stores, the argmax reduction and the next row's phasor loads.
+        // per-lane running maxima over increasing lag index: strict '>' keeps the first
+        T bv_lo = T(0), bv_hi = T(0);
+        int bi_lo = 0, bi_hi = 0;
+        T *const out = A.surface ? A.surface + (size_t)g * F_L : nullptr;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? F_L * (int)sizeof(T) : 0, 0x00020000);
+        const int gc = gn < A.total ? gn : A.total - 1;  // clamped: a[] is always redefined
+        const __amdgpu_buffer_rsrc_t rs_sig =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) spec[k * 256 + t] = {v[k].x * inv, -v[k].y * inv};
-            wave_lds_fence();
-            __syncthreads();  // next iteration's exchange-1 writes vs this one's reads
-            continue;
-        } else {
-            // ---- spectrum product (xcor_rustfft.rs:64-73) -----------------------
-            const C *spec = A.spec + (size_t)b * (2 * 16 * 256) + chain * (16 * 256);
+        for (int j = 0; j < 4; ++j) {
+            T mlo[2], mhi[2];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = cmul(v[k], spec[k * 256 + t]);
-            // ---- inverse (DIT) pass I: over k2 -> m0 ----------------------------
-            dft16(v);
-            // exchange 3 (wave-local): thread (k0,k1) -> [k0][k1][m0^k1]
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < 16; ++k) Lc[hi4 * 256 + lo4 * 16 + (k ^ lo4)] = v[k];
-            wave_lds_fence();
-            // thread (k0, m0=lo4) gathers over k1, twiddle W_256^(k1*m0)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = Lc[hi4 * 256 + k * 16 + (lo4 ^ k)];
-#pragma unroll
-            for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twB[16 * k]);
-            // ---- pass II: over k1 -> m1 -----------------------------------------
-            dft16(v);
-            // exchange 4: [k0][16*m1 + m0] -> thread j=t gathers over k0
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < 16; ++k) Lc[hi4 * 256 + 16 * k + lo4] = v[k];
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = Lc[k * 256 + t];
-#pragma unroll
-            for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twA[k]);
-            // ---- pass III: over k0 -> y[t + 256*m2], m2 = register ---------------
-            dft16(v);
-
-            // ---- last radix-2 stage across the lane halves + epilogue -----------
-            // after the swap: lanes 0-31 hold (E,O)[t+256*(8+i)], lanes 32-63 (E,O)[t+256*i]
-            T bv = T(0);
-            uint32_t bi = 0;
-            T *out = A.surface ? A.surface + (size_t)g * F_L : nullptr;
-            const int mbase = t + (chain == 0 ? 2048 : 0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int u = 0; u < 2; ++u) {
+                const int i = 2 * j + u;
                 C o = v[i], e = v[8 + i];
                 swap32(e, o);
                 const C w32 = {(T)W32_COS[i], (T)W32_SIN[i]};  // W_32^i
                 const C z = cmul(cmul(o, tbase), w32);
-                const T m_lo = norm_sqr(e + z);   // mod.rs:147
-                const T m_hi = norm_sqr(e - z);
-                const int m = mbase + 256 * i;
-                if (out) {
-                    out[m] = m_lo;
-                    out[m + F_N] = m_hi;
-                }
-                arg_merge(bv, bi, m_lo, (uint32_t)m);
-                arg_merge(bv, bi, m_hi, (uint32_t)(m + F_N));
+                mlo[u] = norm_sqr(e + z);  // mod.rs:147
+                mhi[u] = norm_sqr(e - z);
+                if (mlo[u] > bv_lo) { bv_lo = mlo[u]; bi_lo = i; }
+                if (mhi[u] > bv_hi) { bv_hi = mhi[u]; bi_hi = i; }
+                a[i] = bload(rs_sig, voff_sig, (unsigned)(256 * i * sizeof(C)), (C *)nullptr);
+                a[8 + i] = bload(rs_sig, voff_sig, (unsigned)(256 * (8 + i) * sizeof(C)), (C *)nullptr);
             }
-            wave_arg_reduce(bv, bi);
+            // even lane keeps register row 2j, odd lane row 2j+1; each gets the partner's value
+            const T slo = dpp_xor1<T>(odd ? mlo[0] : mlo[1]);
+            const T shi = dpp_xor1<T>(odd ? mhi[0] : mhi[1]);
+            const int m = mpair + 256 * (2 * j + (odd ? 1 : 0));
+            store_pair_wt(rs, (unsigned)(m * sizeof(T)), odd ? slo : mlo[0], odd ? mlo[1] : slo);
+            store_pair_wt(rs, (unsigned)((m + F_N) * sizeof(T)), odd ? shi : mhi[0], odd ? mhi[1] : shi);
+        }
+        CAF_STAMP(15);
+        // lags m (lo part) all precede lags m + 4096 (hi part): init (0.0, lag 0) like mod.rs:143
+        T bv = bv_lo;
+        uint32_t bi = bv_lo > T(0) ? (uint32_t)(mbase + 256 * bi_lo) : 0u;
+        if (bv_hi > bv) { bv = bv_hi; bi = (uint32_t)(mbase + 256 * bi_hi + F_N); }
+        wave_arg_reduce_dpp(bv, bi);
+        {
             T *sv = reinterpret_cast<T *>(scratch + parity * 128);
             uint32_t *si = reinterpret_cast<uint32_t *>(scratch + parity * 128 + 64);
-            if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
-            __syncthreads();  // also orders exchange-4 reads before the next exchange-1 writes
-            if (tid == 0) {
+            if (L.lane == 63) { sv[L.wave] = bv; si[L.wave] = bi; }
+        }
+        CAF_STAMP(16);
+        if constexpr (DIAG) {
+            if (blockIdx.x == 0 && L.lane == 0 && iter < 32) {
 #pragma unroll
-                for (int w = 1; w < 8; ++w) arg_merge(bv, bi, sv[w], si[w]);
-                A.row_idx[g] = bi;
-                A.row_val[g] = bv;
+                for (int i = 0; i < F_NSTAMP; ++i) A.dbg[((size_t)iter * 8 + L.wave) * F_NSTAMP + i] = st[i];
             }
         }
+        prev_g = g;
+        g = gn;
+    }
+    // last row's result
+    __syncthreads();
+    if (L.tid == 0 && prev_g >= 0) {
+        const T *sv = reinterpret_cast<const T *>(scratch + (parity ^ 1) * 128);
+        const uint32_t *si = reinterpret_cast<const uint32_t *>(scratch + (parity ^ 1) * 128 + 64);
+        T bv = sv[0];
+        uint32_t bi = si[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) arg_merge(bv, bi, sv[w], si[w]);
+        A.row_idx[prev_g] = bi;
+        A.row_val[prev_g] = bv;
     }
 }
 

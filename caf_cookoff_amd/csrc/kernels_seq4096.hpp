@@ -1,0 +1,274 @@
+// kernels_seq4096.hpp -- "sequential-chain" Doppler-row kernel for n = 4096 (L = 8192).
+//
+// Same mathematics and the same LDS exchange geometry as kernels_fused4096.hpp, but one
+// 256-thread workgroup (4 waves, one per SIMD) owns a row and runs the EVEN-bin chain and
+// then the ODD-bin chain in the same threads:
+//   * LDS per workgroup = ONE padded chain (4352 complex) + the 256-entry W_256 table
+//     = 72.3 KiB (f64), so TWO workgroups are resident per CU.  They share nothing and hit
+//     their barriers independently: while one sits in an LDS exchange (write-limited,
+//     ~79 B/clk/CU) or waits on L2, the other has the VALU.  In the 512-thread kernel all 8
+//     waves are in the same phase and the two pipes run serially (profiles/r01_*).
+//   * both chain outputs E[m], O[m] of a thread are in its own registers, so the last
+//     radix-2 stage needs no cross-lane traffic at all.
+//   * register budget: 64 (v) + 64 (E stash) + twiddles.  Only W^(t), W^(2t), W^(3t), W^(4t),
+//     W^(8t), W^(12t) are held (24 VGPRs); the other nine W^(t(4a+b)) = W^(4at) W^(bt) cost one
+//     extra complex multiply each per use (+4 % VALU).
+#pragma once
+#include "kernels_fused4096.hpp"
+
+namespace caf {
+
+constexpr int S_THREADS = 256;
+
+template <typename T>
+constexpr size_t seq_lds_bytes() { return (F_CHAIN + 256) * sizeof(cpx<T>) + 64; }
+
+struct SeqLane {
+    int tid, lane, wave, t, hi4, lo4, pA, pB, pC;
+    __device__ __forceinline__ SeqLane()
+    {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        wave = tid >> 6;
+        t = tid;
+        hi4 = t >> 4;
+        lo4 = t & 15;
+        pA = t + hi4;
+        pB = hi4 * F_BLK + lo4;
+        pC = hi4 * F_BLK + 17 * lo4;
+    }
+};
+
+// the six held twiddles W_4096^(t*k), k in {1,2,3,4,8,12}
+template <typename T>
+struct TwSet {
+    cpx<T> w1, w2, w3, w4, w8, w12;
+};
+
+// x * W_4096^(t*k) for a compile-time k (after unrolling): k = 4a + b -> W^(4a t) * W^(b t)
+template <typename T>
+__device__ __forceinline__ cpx<T> twA_k(cpx<T> x, int k, const TwSet<T> &w)
+{
+    const int a = k >> 2, b = k & 3;
+    if (a == 1) x = cmul(x, w.w4);
+    if (a == 2) x = cmul(x, w.w8);
+    if (a == 3) x = cmul(x, w.w12);
+    if (b == 1) x = cmul(x, w.w1);
+    if (b == 2) x = cmul(x, w.w2);
+    if (b == 3) x = cmul(x, w.w3);
+    return x;
+}
+
+template <typename T>
+__device__ __forceinline__ void apply_twA(cpx<T> (&v)[16], const TwSet<T> &w)
+{
+    v[1] = cmul(v[1], w.w1);
+    v[2] = cmul(v[2], w.w2);
+    v[3] = cmul(v[3], w.w3);
+    v[4] = cmul(v[4], w.w4);
+    v[5] = cmul(cmul(v[5], w.w4), w.w1);
+    v[6] = cmul(cmul(v[6], w.w4), w.w2);
+    v[7] = cmul(cmul(v[7], w.w4), w.w3);
+    v[8] = cmul(v[8], w.w8);
+    v[9] = cmul(cmul(v[9], w.w8), w.w1);
+    v[10] = cmul(cmul(v[10], w.w8), w.w2);
+    v[11] = cmul(cmul(v[11], w.w8), w.w3);
+    v[12] = cmul(v[12], w.w12);
+    v[13] = cmul(cmul(v[13], w.w12), w.w1);
+    v[14] = cmul(cmul(v[14], w.w12), w.w2);
+    v[15] = cmul(cmul(v[15], w.w12), w.w3);
+}
+
+// One chain of one row: needle samples -> y[m2] = IDFT_4096(C_chain)[t + 256*m2].
+// 3 workgroup barriers; exchanges 2 and 3 are wave-local.
+// ABL (measurement builds only, wrong results): bit0 = no LDS traffic/barriers (values stay
+// in registers), bit1 = no global loads (operands synthesised), bit2 = no butterfly math.
+template <typename T>
+__device__ __forceinline__ void keep(cpx<T> &x)
+{
+    asm volatile("" : "+v"(x.x), "+v"(x.y));
+}
+#define LDS_W(expr_addr, val) do { if constexpr (!(ABL & 1)) { expr_addr = (val); } else { C tmp__ = (val); keep(tmp__); v[k & 15] = tmp__; } } while (0)
+
+template <typename T, int CH, int ABL = 0>
+__device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], const __amdgpu_buffer_rsrc_t rs_sig,
+                                          const __amdgpu_buffer_rsrc_t rs_spec, const cpx<T> *ph,
+                                          const cpx<T> cfac, const TwSet<T> &tw, const cpx<T> *twB,
+                                          cpx<T> *Lc, const SeqLane &L)
+{
+    using C = cpx<T>;
+    const unsigned voff_sig = (unsigned)(L.t * sizeof(C));
+    const unsigned voff_spec = (unsigned)((CH * 4096 + L.t) * sizeof(C));
+    // ---- mixer (mod.rs:46-65) fused into the first butterfly's operands -----------------
+    {
+        C a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if constexpr (ABL & 2) { a[q] = C{T(q + 1), T(L.t)}; keep(a[q]); }
+            else a[q] = bload(rs_sig, voff_sig, (unsigned)(256 * q * sizeof(C)), (C *)nullptr);
+        }
+        C pb = cmul(ph[L.lo4], ph[16 + L.hi4]);
+        if (CH) pb = cmul(pb, cfac);
+        const C *ps = ph + 32 + CH * 16;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = conj(cmul(cmul(a[q], pb), ps[q]));
+    }
+    // ---- forward (DIF) ------------------------------------------------------------------
+    if constexpr (ABL & 1) {
+        dft16(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v[k] = twA_k(v[k], k, tw); keep(v[k]); }
+        dft16(v);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { v[k] = cmul(v[k], tw.w3); keep(v[k]); }
+    } else {
+        dft16_sink(v, [&](int k, C x) { Lc[L.pA + k * F_BLK] = twA_k(x, k, tw); });
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
+        dft16_sink(v, [&](int k, C x) { Lc[L.pB + 17 * k] = k ? cmul(x, twB[16 * k]) : x; });
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pC + k];
+    }
+    dft16(v);
+    // ---- spectrum product (xcor_rustfft.rs:64-73) ------------------------------------------
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        C hk;
+        if constexpr (ABL & 2) { hk = C{T(1), T(k)}; keep(hk); }
+        else hk = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
+        v[k] = cmul(v[k], hk);
+    }
+    // ---- inverse (DIT) ----------------------------------------------------------------------
+    if constexpr (ABL & 1) {
+        dft16(v);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { v[k] = cmul(v[k], tw.w2); keep(v[k]); }
+        dft16(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) keep(v[k]);
+    } else {
+        wave_lds_fence();
+        dft16_sink(v, [&](int k, C x) { Lc[L.pC + k] = x; });
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twB[16 * k]);
+        wave_lds_fence();
+        dft16_sink(v, [&](int k, C x) { Lc[L.pB + 17 * k] = x; });
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pA + k * F_BLK];
+        __syncthreads();  // all LDS reads of this chain done: the next chain may write
+    }
+    apply_twA(v, tw);
+    dft16(v);
+}
+
+// W_32^m2, m2 < 16
+__device__ constexpr double W32C16[16] = {1.0, 0.98078528040323044912618223613424, 0.92387953251128675612818318939679,
+                                          0.83146961230254523707878837761791, 0.70710678118654752440084436210485,
+                                          0.55557023301960222474283081394853, 0.38268343236508977172845998403040,
+                                          0.19509032201612826784828486847702, 0.0, -0.19509032201612826784828486847702,
+                                          -0.38268343236508977172845998403040, -0.55557023301960222474283081394853,
+                                          -0.70710678118654752440084436210485, -0.83146961230254523707878837761791,
+                                          -0.92387953251128675612818318939679, -0.98078528040323044912618223613424};
+__device__ constexpr double W32S16[16] = {0.0, 0.19509032201612826784828486847702, 0.38268343236508977172845998403040,
+                                          0.55557023301960222474283081394853, 0.70710678118654752440084436210485,
+                                          0.83146961230254523707878837761791, 0.92387953251128675612818318939679,
+                                          0.98078528040323044912618223613424, 1.0, 0.98078528040323044912618223613424,
+                                          0.92387953251128675612818318939679, 0.83146961230254523707878837761791,
+                                          0.70710678118654752440084436210485, 0.55557023301960222474283081394853,
+                                          0.38268343236508977172845998403040, 0.19509032201612826784828486847702};
+
+// STORE: 0 = 16-B write-through (sc1), 1 = 16-B plain, 2 = 16-B nontemporal, 3 = no surface store
+// (1-3 are measurement variants, selected with CAF_STORE_MODE; the product launches 0).
+template <typename T, int STORE = 0, int ABL = 0>
+__global__ __launch_bounds__(S_THREADS, 2) void k_seq_rows(const FusedArgs<T> A)
+{
+    using C = cpx<T>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[seq_lds_bytes<T>()];
+    C *const Lc = reinterpret_cast<C *>(smem);
+    C *const twb = Lc + F_CHAIN;  // twb[k*16 + lo] = W_256^(lo*k)
+    unsigned char *const scratch = smem + (F_CHAIN + 256) * sizeof(C);
+    const SeqLane L;
+
+    TwSet<T> tw;
+    tw.w1 = A.tab.tw4096[L.t * 1];
+    tw.w2 = A.tab.tw4096[L.t * 2];
+    tw.w3 = A.tab.tw4096[L.t * 3];
+    tw.w4 = A.tab.tw4096[L.t * 4];
+    tw.w8 = A.tab.tw4096[L.t * 8];
+    tw.w12 = A.tab.tw4096[L.t * 12];
+    twb[L.tid] = A.tab.tw4096[16 * (L.tid & 15) * (L.tid >> 4)];
+    const C *const twB = twb + L.lo4;
+    const C th = A.tab.th[L.t];       // T^t = e^{2*pi*i*t/8192}
+    const C cfac = conj(th);          // odd chain input rotation e^{-2*pi*i*t/8192}
+    const int mpair = L.t & ~1;
+    const bool odd = L.lane & 1;
+    __syncthreads();
+
+    for (int g = blockIdx.x; g < A.total; g += gridDim.x) {
+        const int b = g / A.rows, r = g - b * A.rows;
+        const C *ph = A.phasor + (size_t)r * 64;
+        const __amdgpu_buffer_rsrc_t rs_sig =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)b * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(A.spec + (size_t)b * (2 * 16 * 256)), 0, 2 * 16 * 256 * (int)sizeof(C), 0x00020000);
+        C e[16], o[16];
+        seq_chain<T, 0, ABL>(e, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L);
+        seq_chain<T, 1, ABL>(o, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L);
+
+        // ---- last radix-2 stage (in registers) + |.|^2 + argmax + 16-B write-through stores --
+        T bv_lo = T(0), bv_hi = T(0);
+        int bi_lo = 0, bi_hi = 0;
+        T *const out = A.surface ? A.surface + (size_t)g * F_L : nullptr;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? F_L * (int)sizeof(T) : 0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            T mlo[2], mhi[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = 2 * j + u;  // m = t + 256*i
+                const C w32 = {(T)W32C16[i], (T)W32S16[i]};
+                const C z = cmul(cmul(o[i], th), w32);  // T^m * O[m]
+                mlo[u] = norm_sqr(e[i] + z);            // mod.rs:147
+                mhi[u] = norm_sqr(e[i] - z);
+                if (mlo[u] > bv_lo) { bv_lo = mlo[u]; bi_lo = i; }
+                if (mhi[u] > bv_hi) { bv_hi = mhi[u]; bi_hi = i; }
+            }
+            const T slo = dpp_xor1<T>(odd ? mlo[0] : mlo[1]);
+            const T shi = dpp_xor1<T>(odd ? mhi[0] : mhi[1]);
+            const int m = mpair + 256 * (2 * j + (odd ? 1 : 0));
+            if constexpr (STORE != 3) {
+                constexpr int AUX = STORE == 0 ? CAF_AUX_SC1 : STORE == 2 ? 2 : 0;
+                store_pair_aux<AUX>(rs, (unsigned)(m * sizeof(T)), odd ? slo : mlo[0], odd ? mlo[1] : slo);
+                store_pair_aux<AUX>(rs, (unsigned)((m + F_N) * sizeof(T)), odd ? shi : mhi[0], odd ? mhi[1] : shi);
+            } else {
+                asm volatile("" ::"v"(slo), "v"(shi));
+            }
+        }
+        T bv = bv_lo;
+        uint32_t bi = bv_lo > T(0) ? (uint32_t)(L.t + 256 * bi_lo) : 0u;
+        if (bv_hi > bv) { bv = bv_hi; bi = (uint32_t)(L.t + 256 * bi_hi + F_N); }
+        wave_arg_reduce_dpp(bv, bi);
+        T *sv = reinterpret_cast<T *>(scratch);
+        uint32_t *si = reinterpret_cast<uint32_t *>(scratch + 32);
+        if (L.lane == 63) { sv[L.wave] = bv; si[L.wave] = bi; }
+        __syncthreads();
+        if (L.tid == 0) {
+            bv = sv[0];
+            bi = si[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) arg_merge(bv, bi, sv[w], si[w]);
+            A.row_idx[g] = bi;
+            A.row_val[g] = bv;
+        }
+        // scratch is rewritten only after the next row's six barriers: no extra barrier needed
+    }
+}
+
+}  // namespace caf
