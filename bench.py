@@ -83,7 +83,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="surfaces per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="surfaces per GPU per step (32 x 400 rows = 25 rows per "
+                    "resident workgroup on 256 CUs x 2)")
     ap.add_argument("--dtype", choices=["c128", "c64"], default="c128")
     ap.add_argument("--nfreq", type=int, default=400)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -135,20 +136,15 @@ def main():
     rval = torch.empty((nsurf, rows), dtype=rdt, device=dev)
     peak = torch.empty((nsurf, 4), dtype=torch.float64, device=dev)  # caf_peak records (32 B)
     peak_i = peak.view(torch.int64)
-    BIG = torch.iinfo(torch.int64).max
+    from caf_cookoff_amd.dist import reduce_global_peak
 
     def step():
         plan.surface_dev(nd.data_ptr(), hs.data_ptr(), nsurf, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(),
                          peak.data_ptr())
         if world == 1:
             return None
-        # global peak per surface: max over ranks, then lowest (global_row, idx) among the holders
-        val = peak[:, 0].clone()
-        dist.all_reduce(val, op=dist.ReduceOp.MAX)
-        key = torch.where((peak[:, 0] == val) & (peak_i[:, 3] >= 0), (peak_i[:, 3] << 32) | peak_i[:, 2],
-                          torch.full_like(peak_i[:, 3], BIG))
-        dist.all_reduce(key, op=dist.ReduceOp.MIN)
-        return val, key
+        # find_peak across the row shards: RCCL all-reduce(max) + all-reduce(min) on 8 B per surface
+        return reduce_global_peak(peak[:, 0], peak_i[:, 3], peak_i[:, 2])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -168,10 +164,9 @@ def main():
             g_idx = pk["idx"].astype(np.int64)
             g_freq = pk["freq"]
         else:
-            val, key = out
-            key = key.cpu().numpy()
-            g_idx = key & 0xffffffff
-            g_freq = freqs[(key >> 32).astype(np.int64)]
+            gmax, grow, gidx = out
+            g_idx = gidx.cpu().numpy()
+            g_freq = freqs[grow.cpu().numpy()]
         for b in range(nsurf):
             want_f = freqs[np.argmin(np.abs(freqs - fos[b]))]
             assert int(g_idx[b]) == lags[b], f"surface {b}: tau {g_idx[b]} != {lags[b]}"

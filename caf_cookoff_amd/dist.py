@@ -1,0 +1,62 @@
+"""Multi-GPU decomposition of the CAF path: contiguous Doppler-row shards + one tiny
+reduction for the global peak.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm,
+"gloo" on CPU for tests).  Rows are independent (mod.rs:135-162 carries no cross-row
+state), so there is NO data-path collective: every rank holds the (replicated, 128 KiB)
+inputs, computes rows [r*F/G, (r+1)*F/G) of every surface in the batch and keeps its
+slab of the surface.  The only exchange is find_peak (mod.rs:31-42):
+
+    gmax = all_reduce(local peak value, MAX)
+    key  = (global_row << 32 | idx)  if local value == gmax and the rank has a peak
+           else INT64_MAX
+    key  = all_reduce(key, MIN)          -> lowest global row among equal peaks wins,
+                                            which is the reference's first-strictly-greater scan
+
+RCCL has no MAXLOC; two 8-byte-per-surface all-reduces are latency-bound (a few us over
+xGMI) and are issued once per batch, not per surface.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+NO_PEAK_KEY = torch.iinfo(torch.int64).max
+
+
+def encode_key(row: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """(global row, lag index) -> sortable int64; row < 2^31, idx < 2^32."""
+    return (row.to(torch.int64) << 32) | idx.to(torch.int64)
+
+
+def decode_key(key: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (row, idx); row = -1 where no rank had a peak > 0 (mod.rs:32-35 initial max)."""
+    none = key == NO_PEAK_KEY
+    row = torch.where(none, torch.full_like(key, -1), key >> 32)
+    idx = torch.where(none, torch.zeros_like(key), key & 0xFFFFFFFF)
+    return row, idx
+
+
+def reduce_global_peak(val: torch.Tensor, row: torch.Tensor, idx: torch.Tensor,
+                       group: Optional[dist.ProcessGroup] = None
+                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Combine per-rank shard peaks into the global find_peak result.
+
+    val/row/idx: [batch] local peak value (float64), GLOBAL row position (-1 = no peak)
+    and lag index of this rank's shard (the caf_peak records of caf_surface_dev).
+    Returns (gmax, grow, gidx), identical on every rank.  Works on CPU (gloo) and GPU
+    (nccl/RCCL) tensors; without an initialised process group it is the identity."""
+    val = val.to(torch.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        has = row >= 0
+        return (torch.where(has, val, torch.zeros_like(val)), torch.where(has, row, torch.full_like(row, -1)),
+                torch.where(has, idx, torch.zeros_like(idx)))
+    gmax = torch.where(row >= 0, val, torch.zeros_like(val)).clone()
+    dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+    mine = (row >= 0) & (val == gmax) & (gmax > 0)
+    key = torch.where(mine, encode_key(row, idx), torch.full_like(row, NO_PEAK_KEY, dtype=torch.int64))
+    dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)
+    grow, gidx = decode_key(key)
+    return gmax, grow, gidx
