@@ -1,0 +1,157 @@
+// caf_hip.hpp -- header-only C++ mirror of the reference's operator surface over the C ABI.
+//
+// Reference (caf_rust/src/caf/mod.rs): `trait CafSurface` with associated functions
+// caf_surface (:26-27), find_peak (:31-42), apply_freq_shift (:46-65), the row record
+// CafSurfaceRow (:17-22), and xcor_rustfft::Xcor::{new, run, clone} (xcor_rustfft.rs:14-93).
+// `caf::CafHip` is the backend an eighth `impl CafSurface for CafHip` would be (the Rust
+// stub is in INTEGRATION.md); the reference's other helpers used by its callers
+// (utils.rs read_file_c64, test.rs gen_float_shifts/load_files) are mirrored too so that
+// tests and the demo read like the reference's.  Errors: the reference panics
+// (assert!/unwrap); here a std::runtime_error carries caf_last_error_string().
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "caf_hip.h"
+
+namespace caf {
+
+using Complex64 = std::complex<double>;  // num_complex::Complex64 == {re: f64, im: f64}
+
+struct CafSurfaceRow {  // mod.rs:17-22
+    double freq;
+    std::vector<double> xcor_mag;
+    std::size_t xcor_peak_idx;
+    double xcor_peak_val;
+};
+
+inline void check(int rc, const char *what)
+{
+    if (rc != CAF_OK) throw std::runtime_error(std::string(what) + ": " + caf_last_error_string());
+}
+
+// One context per thread (the C ABI's contexts are not thread-safe).
+inline caf_ctx *default_ctx()
+{
+    struct Holder {
+        caf_ctx *c = nullptr;
+        Holder() { check(caf_ctx_create(0, &c), "caf_ctx_create"); }
+        ~Holder() { caf_ctx_destroy(c); }
+    };
+    static thread_local Holder h;
+    return h.c;
+}
+
+struct CafHip {  // `pub struct CafHip {}  impl CafSurface for CafHip`
+    // mod.rs:26-27.  Rows come back in freq-list order (like CafRustFFT / the rayon collect).
+    static std::vector<CafSurfaceRow> caf_surface(const std::vector<Complex64> &needle,
+                                                  const std::vector<Complex64> &haystack,
+                                                  const std::vector<double> &freqs_hz, uint32_t fs)
+    {
+        if (needle.size() != haystack.size())  // Xcor::run's assert (xcor_rustfft.rs:54-55)
+            throw std::runtime_error("assertion failed: a.len() == self.n");
+        const std::size_t n = needle.size(), F = freqs_hz.size(), L = 2 * n;
+        std::vector<double> surf(F * L), val(F);
+        std::vector<uint64_t> idx(F);
+        caf_peak pk;
+        check(caf_surface_c128(default_ctx(), reinterpret_cast<const double *>(needle.data()),
+                               reinterpret_cast<const double *>(haystack.data()), n, freqs_hz.data(), F, fs,
+                               surf.data(), idx.data(), val.data(), &pk),
+              "caf_surface_c128");
+        std::vector<CafSurfaceRow> rows(F);
+        for (std::size_t r = 0; r < F; ++r)
+            rows[r] = CafSurfaceRow{freqs_hz[r], std::vector<double>(surf.begin() + r * L, surf.begin() + (r + 1) * L),
+                                    static_cast<std::size_t>(idx[r]), val[r]};
+        return rows;
+    }
+
+    // mod.rs:31-42: consumes the surface; first strictly-greater row wins; empty -> (0.0, 0).
+    static std::pair<double, std::size_t> find_peak(std::vector<CafSurfaceRow> arr)
+    {
+        std::vector<double> fr(arr.size()), val(arr.size());
+        std::vector<uint64_t> idx(arr.size());
+        for (std::size_t r = 0; r < arr.size(); ++r) {
+            fr[r] = arr[r].freq;
+            idx[r] = arr[r].xcor_peak_idx;
+            val[r] = arr[r].xcor_peak_val;
+        }
+        caf_peak pk;
+        check(caf_find_peak(default_ctx(), fr.data(), idx.data(), val.data(), arr.size(), &pk), "caf_find_peak");
+        return {pk.freq, static_cast<std::size_t>(pk.idx)};
+    }
+
+    // mod.rs:46-65
+    static std::vector<Complex64> apply_freq_shift(const std::vector<Complex64> &samples, double freq_shift,
+                                                   uint32_t fs)
+    {
+        std::vector<Complex64> out(samples.size());
+        check(caf_apply_freq_shift_c128(default_ctx(), reinterpret_cast<const double *>(samples.data()),
+                                        samples.size(), freq_shift, fs, reinterpret_cast<double *>(out.data())),
+              "caf_apply_freq_shift_c128");
+        return out;
+    }
+};
+
+class Xcor {  // xcor_rustfft.rs:14-93
+  public:
+    explicit Xcor(std::size_t n) : n_(n)
+    {
+        if (n == 0 || (n & (n - 1))) throw std::runtime_error("Xcor::new: n must be a power of two");
+    }
+    std::vector<Complex64> run(const std::vector<Complex64> &a, const std::vector<Complex64> &b) const
+    {
+        if (a.size() != n_) throw std::runtime_error("assertion failed: a.len() == self.n");
+        if (b.size() != n_) throw std::runtime_error("assertion failed: b.len() == self.n");
+        std::vector<Complex64> out(n_);
+        check(caf_xcor_c128(default_ctx(), reinterpret_cast<const double *>(a.data()),
+                            reinterpret_cast<const double *>(b.data()), n_, reinterpret_cast<double *>(out.data())),
+              "caf_xcor_c128");
+        return out;
+    }
+    Xcor clone() const { return Xcor(n_); }  // plans are cached per n inside the context
+
+  private:
+    std::size_t n_;
+};
+
+// utils.rs:10-35: packed LE f32 I/Q pairs -> Complex64
+inline std::vector<Complex64> read_file_c64(const std::string &filename)
+{
+    std::ifstream f(filename, std::ios::binary);
+    if (!f) throw std::runtime_error("read_file_c64: cannot open " + filename);
+    std::vector<char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (buf.size() % 8) throw std::runtime_error("read_file_c64: trailing partial sample");
+    const float *p = reinterpret_cast<const float *>(buf.data());
+    std::vector<Complex64> out(buf.size() / 8);
+    for (std::size_t i = 0; i < out.size(); ++i) out[i] = Complex64(p[2 * i], p[2 * i + 1]);
+    return out;
+}
+
+// test.rs:319-331: haystack.resize(needle.len(), 0)
+inline std::pair<std::vector<Complex64>, std::vector<Complex64>> load_files(const std::string &needle_filename,
+                                                                           const std::string &haystack_filename)
+{
+    auto needle = read_file_c64(needle_filename);
+    auto haystack = read_file_c64(haystack_filename);
+    haystack.resize(needle.size(), Complex64(0.0, 0.0));
+    return {needle, haystack};
+}
+
+// test.rs:335-352
+inline std::vector<double> gen_float_shifts(double start, double end, double step)
+{
+    const int32_t s = static_cast<int32_t>(start * 1000.0), e = static_cast<int32_t>(end * 1000.0);
+    const std::size_t st = static_cast<std::size_t>(step * 1000.0);
+    if (st == 0) throw std::runtime_error("step_by(0)");
+    std::vector<double> shifts;
+    for (int64_t m = s; m < e; m += static_cast<int64_t>(st)) shifts.push_back(static_cast<double>(m) / 1e3);
+    return shifts;
+}
+
+}  // namespace caf

@@ -1,0 +1,75 @@
+// Integration tests for chirp 0-9 through the C++ mirror of the CafSurface trait --
+// the C++ counterpart of the reference's caf_rust/tests/test.rs (same files, same shift
+// lists, same exact-equality assertions on (freq, samp_idx)).
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "caf_hip.hpp"
+
+using namespace caf;
+
+static int failures = 0;
+static std::string data_dir = "tests/golden/data/";
+
+#define ASSERT_EQ(a, b)                                                                              \
+    do {                                                                                             \
+        if (!((a) == (b))) {                                                                         \
+            std::printf("  assertion failed: `(left == right)` left: `%.17g`, right: `%.17g` (%s:%d)\n", \
+                        (double)(a), (double)(b), __FILE__, __LINE__);                               \
+            ++failures;                                                                              \
+        }                                                                                            \
+    } while (0)
+
+static void kat(const char *name, const char *needle_file, const char *haystack_file, double start, double end,
+                double step, double want_freq, std::size_t want_idx)
+{
+    // Read the chirp reference and modified files (test.rs:150-153 style)
+    auto files = load_files(data_dir + needle_file, data_dir + haystack_file);
+    auto shifts = gen_float_shifts(start, end, step);
+    // Get the CAF estimates
+    auto surface = CafHip::caf_surface(files.first, files.second, shifts, 48000);
+    auto peak = CafHip::find_peak(std::move(surface));
+    // Confirm correct results
+    const int before = failures;
+    ASSERT_EQ(peak.first, want_freq);
+    ASSERT_EQ(peak.second, want_idx);
+    std::printf("test %s ... %s\n", name, failures == before ? "ok" : "FAILED");
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1) data_dir = std::string(argv[1]) + "/";
+    kat("test_hip_chirp0", "chirp_0_raw.c64", "chirp_0_T+202samp_F+69.25Hz.c64", -100.0, 100.0, 0.25, 69.25, 202);
+    kat("test_hip_chirp1", "chirp_1_raw.c64", "chirp_1_T+78samp_F+35.99Hz.c64", -50.0, 50.0, 1.0, 36.0, 78);
+    kat("test_hip_chirp2", "chirp_2_raw.c64", "chirp_2_T+169samp_F+32.16Hz.c64", 30.0, 35.0, 0.05, 32.15, 169);
+    kat("test_hip_chirp3", "chirp_3_raw.c64", "chirp_3_T+151samp_F-76.22Hz.c64", -100.0, 100.0, 0.25, -76.25, 151);
+    kat("test_hip_chirp4", "chirp_4_raw.c64", "chirp_4_T+70samp_F+82.89Hz.c64", 80.0, 100.0, 0.1, 82.9, 70);
+    kat("test_hip_chirp5", "chirp_5_raw.c64", "chirp_5_T+177samp_F-92.72Hz.c64", -100.0, 100.0, 0.25, -92.75, 177);
+    kat("test_hip_chirp6", "chirp_6_raw.c64", "chirp_6_T+15samp_F-49.69Hz.c64", -100.0, 100.0, 0.25, -49.75, 15);
+    kat("test_hip_chirp7", "chirp_7_raw.c64", "chirp_7_T+84samp_F+68.26Hz.c64", -100.0, 100.0, 0.25, 68.25, 84);
+    kat("test_hip_chirp8", "chirp_8_raw.c64", "chirp_8_T+80samp_F-46.28Hz.c64", -100.0, 100.0, 0.25, -46.25, 80);
+    kat("test_hip_chirp9", "chirp_9_raw.c64", "chirp_9_T+176samp_F+61.49Hz.c64", -100.0, 100.0, 0.5, 61.5, 176);
+    // apply_freq_shift: sample 0 untouched, |out| == |in| (mod.rs:57-61)
+    {
+        auto needle = read_file_c64(data_dir + "chirp_0_raw.c64");
+        auto out = CafHip::apply_freq_shift(needle, 77.77, 48000);  // caf_bench.rs:172-177
+        const int before = failures;
+        ASSERT_EQ(out[0].real(), needle[0].real());
+        ASSERT_EQ(out[0].imag(), needle[0].imag());
+        ASSERT_EQ(out.size(), needle.size());
+        std::printf("test apply_freq_shift ... %s\n", failures == before ? "ok" : "FAILED");
+    }
+    // Xcor length assert (xcor_rustfft.rs:54-55)
+    {
+        bool threw = false;
+        try {
+            Xcor x(8);
+            x.run(std::vector<Complex64>(8), std::vector<Complex64>(4));
+        } catch (const std::runtime_error &) { threw = true; }
+        ASSERT_EQ(threw, true);
+        std::printf("test xcor_length_assert ... %s\n", threw ? "ok" : "FAILED");
+    }
+    std::printf("test result: %s. %d failed\n", failures ? "FAILED" : "ok", failures);
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,32 @@
+"""Builds and runs the C++ host-side mirror of the reference's callers on the GPU:
+tests/cpp/test_kats.cpp (== caf_rust/tests/test.rs) and examples/caf_main.cpp
+(== caf_rust/src/main.rs:10-32, whose output format is checked)."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.run(["make", "-C", str(ROOT / "caf_cookoff_amd" / "csrc")], check=True, capture_output=True)
+    subprocess.run(["make", "-C", str(ROOT / "tests" / "cpp")], check=True, capture_output=True)
+    return ROOT / "tests" / "cpp"
+
+
+def test_cpp_kats(built):
+    r = subprocess.run([str(built / "test_kats"), str(ROOT / "tests" / "golden" / "data")], capture_output=True,
+                       text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("... ok") == 12 and "test result: ok. 0 failed" in r.stdout
+
+
+def test_cpp_main_demo(built):
+    r = subprocess.run([str(built / "caf_main")], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # main.rs:29-31 on the chirp_0 pair with the 0.5 Hz grid -> 69.0 Hz, 202 samples, 202/48 ms
+    assert r.stdout.splitlines() == ["Frequency offset: 69.0Hz", "Time offset: 202 samples (4.208ms)"]
