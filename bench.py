@@ -47,6 +47,22 @@ def algorithmic_bytes(n_surfaces: int, rows_local: int, n: int, dtype: str) -> i
     return n_surfaces * per_surface + rows_local * 8
 
 
+def profiled_traffic(kernel_name: str, nsurf: int, dtype: str):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under
+    profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command, corrected as
+    MI355X_MICROARCH.md prescribes; tools/profile_pack.py).  None if no matching profile."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("*/traffic.json")):
+        try:
+            t = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if t.get("kernel") and t["kernel"] in kernel_name and t.get("surfaces_per_launch") == nsurf and \
+                t.get("dtype") == ("f64" if dtype == "c128" else "f32"):
+            best = (t["traffic_bytes_per_launch"], str(f.relative_to(ROOT)))
+    return best
+
+
 def cpu_baseline(seconds: float, threads: int):
     """C restatement of caf_rust (oracle/caf_oracle.c; 3 FFTs per row like
     xcor_rustfft.rs:58-61, one task per row like CafRustFFTThreadpool) on the
@@ -195,6 +211,7 @@ def main():
         kern_ms = kern_ms_total / max(1, launches)
         abytes = algorithmic_bytes(nsurf, rows, N_SAMP, args.dtype)
         achieved = abytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = profiled_traffic(plan.kernel_name, nsurf, args.dtype) if world == 1 else None
         res = {
             "metric": "CAF surfaces/sec (400 freqs x 8192 samp, c128)" if (F == 400 and args.dtype == "c128")
                       else f"CAF surfaces/sec ({F} freqs x 8192 samp, {args.dtype})",
@@ -207,8 +224,9 @@ def main():
                        "rows_per_gpu": rows, "parallelism": f"doppler-row-shard x{world}" if world > 1 else "single",
                        "kernel_path": plan.path, "device": devname, "cus": cu},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": f"k_fused_rows<{'double' if args.dtype == 'c128' else 'float'},false>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
+                         "kernel": plan.kernel_name,
                          "kernel_ms": kern_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_launch": abytes,
                          "frac_of_achievable_6.29TBs": achieved / HBM_ACHIEVABLE_GBS,

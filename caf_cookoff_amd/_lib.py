@@ -66,6 +66,7 @@ SYMBOLS = [
     ("caf_plan_destroy", _int, [_vp]),
     ("caf_plan_path", ctypes.c_char_p, [_vp]),
     ("caf_plan_rows", _sz, [_vp]),
+    ("caf_plan_kernel_name", ctypes.c_char_p, [_vp]),
     ("caf_surface_dev", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     ("caf_plan_timing_begin", _int, [_vp]),
     ("caf_plan_timing_end", _int, [_vp, _dp, _up]),

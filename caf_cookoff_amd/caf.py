@@ -191,6 +191,7 @@ class Plan:
         self.rows = int(eng.lib.caf_plan_rows(h))
         self.row_begin = int(row_begin)
         self.path = eng.lib.caf_plan_path(h).decode()
+        self.kernel_name = eng.lib.caf_plan_kernel_name(h).decode()
 
     def surface_dev(self, d_needle: int, d_haystack: int, batch: int, d_surface: Optional[int], d_row_idx: int,
                     d_row_val: int, d_peak: int):

@@ -392,6 +392,14 @@ extern "C" int caf_plan_destroy(caf_plan *p)
 
 extern "C" const char *caf_plan_path(const caf_plan *p) { return !p ? "" : p->fused ? "fused4096" : "generic"; }
 extern "C" size_t caf_plan_rows(const caf_plan *p) { return p ? p->rows : 0; }
+extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
+{
+    if (!p) return "";
+    const bool f64 = p->dtype == CAF_C128;
+    if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
+    if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0>" : "caf::k_seq_rows<float, 0, 0>";
+    return f64 ? "caf::k_fused_rows<double, false>" : "caf::k_fused_rows<float, false>";
+}
 
 static int timing_mark(caf_plan *p)
 {

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Pack a gpurun_out/prof_* directory (rocprofv3 csv output of bench.py passes) into a
+profiles/<name>/ directory: kernel_stats.csv, pmc_summary.txt, traffic.json."""
+import csv
+import glob
+import json
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+src, dst = Path(sys.argv[1]), Path(sys.argv[2])
+kernel = sys.argv[3] if len(sys.argv) > 3 else "k_seq_rows"
+dst.mkdir(parents=True, exist_ok=True)
+for f in glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv")):
+    shutil.copy(f, dst / "kernel_stats.csv")
+if (src / "stats_bench.json").exists():
+    shutil.copy(src / "stats_bench.json", dst / "bench_under_rocprof.json")
+files = sorted(glob.glob(str(src / "pmc_*" / "*" / "*counter_collection.csv")))
+out = subprocess.run([sys.executable, str(Path(__file__).parent / "pmc_summary.py"), *files], capture_output=True,
+                     text=True).stdout.replace(str(src) + "/", "")
+(dst / "pmc_summary.txt").write_text(out)
+
+
+def mean_counter(pattern, counter):
+    vals = []
+    for f in glob.glob(str(src / pattern / "*" / "*counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                vals.append(float(row["Counter_Value"]))
+    return sum(vals) / len(vals) if vals else None
+
+
+fetch, write = mean_counter("pmc_fetch", "FETCH_SIZE"), mean_counter("pmc_write", "WRITE_SIZE")
+bench = json.loads((src / "stats_bench.json").read_text()) if (src / "stats_bench.json").exists() else {}
+if fetch is not None and write is not None:
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+    # half of the bytes of 16-B-per-lane streaming reads -> doubled; WRITE_SIZE is exact for
+    # 16-B-per-lane stores.
+    traffic = (2.0 * fetch + write) * 1024.0
+    info = {"kernel": kernel, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "fetch_correction": 2.0,
+            "traffic_bytes_per_launch": traffic,
+            "surfaces_per_launch": bench.get("config", {}).get("surfaces_per_step"),
+            "dtype": bench.get("dtype"), "algorithmic_bytes_per_launch":
+                bench.get("roofline", {}).get("algorithmic_bytes_per_launch")}
+    (dst / "traffic.json").write_text(json.dumps(info, indent=1) + "\n")
+    print(json.dumps(info))
