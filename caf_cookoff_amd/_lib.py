@@ -70,6 +70,12 @@ SYMBOLS = [
     ("caf_surface_dev", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     ("caf_plan_timing_begin", _int, [_vp]),
     ("caf_plan_timing_end", _int, [_vp, _dp, _up]),
+    ("caf_stream_create", _int, [_vp, _sz, _int, _int, ctypes.POINTER(_vp)]),
+    ("caf_stream_destroy", _int, [_vp]),
+    ("caf_stream_host_buffers", _int, [_vp, _int, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    ("caf_stream_submit", _int, [_vp, _int]),
+    ("caf_stream_wait", _int, [_vp, _int, _pp, _up, _vp]),
+    ("caf_stream_surface", _vp, [_vp, _int]),
 ]
 
 _lib = None

@@ -220,6 +220,59 @@ class Plan:
             pass
 
 
+class Stream:
+    """``caf_stream``: double-buffered streaming of host-resident pairs (BASELINE configs[4]).
+    ``buffers(slot)`` are numpy views of the slot's PINNED staging memory; fill them, then
+    ``submit(slot)`` (asynchronous graph replay) and later ``wait(slot)``."""
+
+    PEAK_DTYPE = np.dtype([("val", "<f8"), ("freq", "<f8"), ("idx", "<u8"), ("row", "<i8")])
+
+    def __init__(self, plan: "Plan", batch: int, nslots: int = 2, want_surface: bool = True):
+        self.plan, self.batch, self.nslots = plan, int(batch), int(nslots)
+        h = ctypes.c_void_p()
+        check(plan.eng.lib.caf_stream_create(plan._h, self.batch, self.nslots, int(bool(want_surface)),
+                                             ctypes.byref(h)))
+        self._h = h
+        self._cdt = np.complex128 if plan.dtype == "c128" else np.complex64
+        self._rdt = np.float64 if plan.dtype == "c128" else np.float32
+
+    def buffers(self, slot: int):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        check(self.plan.eng.lib.caf_stream_host_buffers(self._h, int(slot), ctypes.byref(a), ctypes.byref(b)))
+        nbytes = self.batch * self.plan.n * np.dtype(self._cdt).itemsize
+
+        def view(p):
+            buf = (ctypes.c_char * nbytes).from_address(p.value)
+            return np.frombuffer(buf, dtype=self._cdt).reshape(self.batch, self.plan.n)
+        return view(a), view(b)
+
+    def submit(self, slot: int):
+        check(self.plan.eng.lib.caf_stream_submit(self._h, int(slot)))
+
+    def wait(self, slot: int, want_rows: bool = True):
+        peaks = np.zeros(self.batch, dtype=self.PEAK_DTYPE)
+        ridx = np.zeros((self.batch, self.plan.rows), dtype=np.uint64) if want_rows else None
+        rval = np.zeros((self.batch, self.plan.rows), dtype=self._rdt) if want_rows else None
+        check(self.plan.eng.lib.caf_stream_wait(
+            self._h, int(slot), peaks.ctypes.data_as(ctypes.POINTER(CafPeak)),
+            _uptr(ridx) if want_rows else None, ctypes.c_void_p(rval.ctypes.data) if want_rows else None))
+        return peaks, ridx, rval
+
+    def surface_ptr(self, slot: int) -> int:
+        return int(self.plan.eng.lib.caf_stream_surface(self._h, int(slot)) or 0)
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.plan, "_h", None):
+            self.plan.eng.lib.caf_stream_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _default: dict = {}
 
 

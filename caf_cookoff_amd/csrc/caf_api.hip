@@ -91,6 +91,7 @@ struct caf_plan {
     // fused
     void *d_phasor = nullptr;
     DevBuf spec;
+    void *spec_override = nullptr;  // streaming slots bring their own spectrum buffer (they run concurrently)
     // generic
     void *d_tw = nullptr;  // borrowed from ctx cache
     DevBuf wx, wy, hx, hy;
@@ -463,12 +464,12 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
 {
     caf_ctx *c = p->ctx;
     int rc;
-    if ((rc = p->spec.ensure(batch * 2 * 16 * 256 * sizeof(cpx<T>)))) return rc;
+    if (!p->spec_override && (rc = p->spec.ensure(batch * 2 * 16 * 256 * sizeof(cpx<T>)))) return rc;
     FusedArgs<T> a;
     a.phasor = (const cpx<T> *)p->d_phasor;
     a.tab.tw4096 = (const cpx<T> *)c->tw4096[p->dtype];
     a.tab.th = (const cpx<T> *)c->th[p->dtype];
-    a.spec = (cpx<T> *)p->spec.p;
+    a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
     a.rows = (int)p->rows;
     a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr;
     a.dbg = p->dbg;
@@ -489,7 +490,7 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     if ((rc = timing_mark(p))) return rc;
     if (p->variant == 0 && !p->dbg) {
         size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
-        if (per_cu > 2) per_cu = 2;  // 256 VGPRs/wave cap the kernel at 2 waves per SIMD
+        if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();  // VGPR-limited
         static const int wg_per_cu_env = getenv("CAF_WG_PER_CU") ? atoi(getenv("CAF_WG_PER_CU")) : 0;  // measurement only
         if (wg_per_cu_env > 0) per_cu = (size_t)wg_per_cu_env;
         const size_t cap = (size_t)c->cu_count * per_cu;
@@ -690,4 +691,180 @@ extern "C" int caf_find_peak(caf_ctx *c, const double *freqs, const uint64_t *ro
     HIPCHK(hipMemcpyAsync(peak, c->io_peak.p, sizeof(caf_peak), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return CAF_OK;
+}
+
+// --------------------------------------------------------------- streaming --
+struct StreamSlot {
+    hipStream_t stream = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    void *h_needle = nullptr, *h_hay = nullptr;            // pinned
+    void *h_peak = nullptr, *h_ridx = nullptr, *h_rval = nullptr;  // pinned results
+    void *d_needle = nullptr, *d_hay = nullptr, *d_surface = nullptr;
+    void *d_ridx = nullptr, *d_rval = nullptr, *d_peak = nullptr;
+    void *d_spec = nullptr;  // fused plans: this slot's haystack spectra
+    bool own_stream = true;
+};
+
+struct caf_stream {
+    caf_plan *plan = nullptr;
+    size_t batch = 0;
+    std::vector<StreamSlot> slots;
+};
+
+static void stream_free(caf_stream *st)
+{
+    if (!st) return;
+    for (auto &s : st->slots) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.exec) (void)hipGraphExecDestroy(s.exec);
+        if (s.graph) (void)hipGraphDestroy(s.graph);
+        for (void *p : {s.h_needle, s.h_hay, s.h_peak, s.h_ridx, s.h_rval})
+            if (p) (void)hipHostFree(p);
+        for (void *p : {s.d_needle, s.d_hay, s.d_surface, s.d_ridx, s.d_rval, s.d_peak, s.d_spec})
+            if (p) (void)hipFree(p);
+        if (s.stream && s.own_stream) (void)hipStreamDestroy(s.stream);
+    }
+    delete st;
+}
+
+extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want_surface, caf_stream **out)
+{
+    if (!p || !out) return fail(CAF_ERR_BAD_ARG, "caf_stream_create: NULL argument");
+    *out = nullptr;
+    if (batch == 0 || nslots < 2 || nslots > 16) return fail(CAF_ERR_BAD_ARG, "caf_stream_create: batch >= 1, 2 <= nslots <= 16");
+    caf_ctx *c = p->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    caf_stream *st = new (std::nothrow) caf_stream;
+    if (!st) return fail(CAF_ERR_NOMEM, "out of host memory");
+    st->plan = p;
+    st->batch = batch;
+    st->slots.resize(nslots);
+    const size_t in_bytes = batch * p->n * elem_size(p->dtype);
+    const size_t rows = p->rows ? p->rows : 1;
+    const size_t ridx_bytes = batch * rows * sizeof(uint64_t), rval_bytes = batch * rows * real_size(p->dtype);
+    const size_t surf_bytes = batch * rows * p->L * real_size(p->dtype);
+    hipStream_t saved = c->stream;
+    int rc = CAF_OK;
+    auto bail = [&](int code) { c->stream = saved; p->spec_override = nullptr; stream_free(st); return code; };
+#define SCHK(expr)                                                                                         \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess) return bail(fail(CAF_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__))); \
+    } while (0)
+    for (size_t si = 0; si < st->slots.size(); ++si) {
+        StreamSlot &s = st->slots[si];
+        // Fused plans: every slot has private device state -> slots run concurrently on their
+        // own streams.  Generic-path plans share the plan's pass workspaces -> one stream.
+        if (p->fused || si == 0) {
+            SCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        } else {
+            s.stream = st->slots[0].stream;
+            s.own_stream = false;
+        }
+        if (p->fused) SCHK(hipMalloc(&s.d_spec, batch * 2 * 16 * 256 * elem_size(p->dtype)));
+        SCHK(hipHostMalloc(&s.h_needle, in_bytes, hipHostMallocDefault));
+        SCHK(hipHostMalloc(&s.h_hay, in_bytes, hipHostMallocDefault));
+        SCHK(hipHostMalloc(&s.h_peak, batch * sizeof(caf_peak), hipHostMallocDefault));
+        SCHK(hipHostMalloc(&s.h_ridx, ridx_bytes, hipHostMallocDefault));
+        SCHK(hipHostMalloc(&s.h_rval, rval_bytes, hipHostMallocDefault));
+        SCHK(hipMalloc(&s.d_needle, in_bytes));
+        SCHK(hipMalloc(&s.d_hay, in_bytes));
+        SCHK(hipMalloc(&s.d_ridx, ridx_bytes));
+        SCHK(hipMalloc(&s.d_rval, rval_bytes));
+        SCHK(hipMalloc(&s.d_peak, batch * sizeof(caf_peak)));
+        if (want_surface) SCHK(hipMalloc(&s.d_surface, surf_bytes));
+        memset(s.h_needle, 0, in_bytes);
+        memset(s.h_hay, 0, in_bytes);
+    }
+    // Warm-up outside capture: lets the plan allocate its per-batch workspace (hipMalloc is
+    // not capturable), then capture one graph per slot on the slot's own stream.
+    c->stream = st->slots[0].stream;
+    {
+        StreamSlot &s = st->slots[0];
+        SCHK(hipMemcpyAsync(s.d_needle, s.h_needle, in_bytes, hipMemcpyHostToDevice, s.stream));
+        SCHK(hipMemcpyAsync(s.d_hay, s.h_hay, in_bytes, hipMemcpyHostToDevice, s.stream));
+        rc = caf_surface_dev(p, s.d_needle, s.d_hay, batch, s.d_surface, (uint64_t *)s.d_ridx, s.d_rval, (caf_peak *)s.d_peak);
+        if (rc) return bail(rc);
+        SCHK(hipStreamSynchronize(s.stream));
+    }
+    const bool was_timing = p->timing;
+    p->timing = false;  // event records are not wanted inside the graphs
+    for (auto &s : st->slots) {
+        c->stream = s.stream;
+        p->spec_override = s.d_spec;
+        SCHK(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e1 = hipMemcpyAsync(s.d_needle, s.h_needle, in_bytes, hipMemcpyHostToDevice, s.stream);
+        hipError_t e2 = hipMemcpyAsync(s.d_hay, s.h_hay, in_bytes, hipMemcpyHostToDevice, s.stream);
+        rc = caf_surface_dev(p, s.d_needle, s.d_hay, batch, s.d_surface, (uint64_t *)s.d_ridx, s.d_rval, (caf_peak *)s.d_peak);
+        hipError_t e3 = hipMemcpyAsync(s.h_peak, s.d_peak, batch * sizeof(caf_peak), hipMemcpyDeviceToHost, s.stream);
+        hipError_t e4 = p->rows ? hipMemcpyAsync(s.h_ridx, s.d_ridx, ridx_bytes, hipMemcpyDeviceToHost, s.stream) : hipSuccess;
+        hipError_t e5 = p->rows ? hipMemcpyAsync(s.h_rval, s.d_rval, rval_bytes, hipMemcpyDeviceToHost, s.stream) : hipSuccess;
+        hipError_t ec = hipStreamEndCapture(s.stream, &s.graph);
+        p->spec_override = nullptr;
+        p->timing = was_timing;
+        if (rc) return bail(rc);
+        for (hipError_t e : {e1, e2, e3, e4, e5, ec})
+            if (e != hipSuccess) return bail(fail(CAF_ERR_HIP, "graph capture: %s", hipGetErrorString(e)));
+        SCHK(hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0));
+        p->timing = false;
+    }
+    p->timing = was_timing;
+#undef SCHK
+    c->stream = saved;
+    *out = st;
+    return CAF_OK;
+}
+
+extern "C" int caf_stream_destroy(caf_stream *st)
+{
+    if (!st) return CAF_OK;
+    (void)hipSetDevice(st->plan->ctx->device);
+    stream_free(st);
+    return CAF_OK;
+}
+
+static int slot_ok(caf_stream *st, int slot)
+{
+    if (!st) return fail(CAF_ERR_BAD_ARG, "stream is NULL");
+    if (slot < 0 || slot >= (int)st->slots.size()) return fail(CAF_ERR_BAD_ARG, "slot %d out of range", slot);
+    return CAF_OK;
+}
+
+extern "C" int caf_stream_host_buffers(caf_stream *st, int slot, void **needle, void **haystack)
+{
+    int rc = slot_ok(st, slot);
+    if (rc) return rc;
+    if (needle) *needle = st->slots[slot].h_needle;
+    if (haystack) *haystack = st->slots[slot].h_hay;
+    return CAF_OK;
+}
+
+extern "C" int caf_stream_submit(caf_stream *st, int slot)
+{
+    int rc = slot_ok(st, slot);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(st->plan->ctx->device));
+    HIPCHK(hipGraphLaunch(st->slots[slot].exec, st->slots[slot].stream));
+    return CAF_OK;
+}
+
+extern "C" int caf_stream_wait(caf_stream *st, int slot, caf_peak *peaks, uint64_t *row_idx, void *row_val)
+{
+    int rc = slot_ok(st, slot);
+    if (rc) return rc;
+    StreamSlot &s = st->slots[slot];
+    HIPCHK(hipSetDevice(st->plan->ctx->device));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    const size_t rows = st->plan->rows;
+    if (peaks) memcpy(peaks, s.h_peak, st->batch * sizeof(caf_peak));
+    if (row_idx && rows) memcpy(row_idx, s.h_ridx, st->batch * rows * sizeof(uint64_t));
+    if (row_val && rows) memcpy(row_val, s.h_rval, st->batch * rows * real_size(st->plan->dtype));
+    return CAF_OK;
+}
+
+extern "C" void *caf_stream_surface(caf_stream *st, int slot)
+{
+    if (slot_ok(st, slot)) return nullptr;
+    return st->slots[slot].d_surface;
 }

@@ -185,8 +185,13 @@ __device__ constexpr double W32S16[16] = {0.0, 0.1950903220161282678482848684770
 
 // STORE: 0 = 16-B write-through (sc1), 1 = 16-B plain, 2 = 16-B nontemporal, 3 = no surface store
 // (1-3 are measurement variants, selected with CAF_STORE_MODE; the product launches 0).
+// waves per SIMD the register allocator must leave room for: f64 rows need ~230 VGPRs (2),
+// f32 rows fit 168 (3 workgroups of 36 KiB LDS per CU; 128 VGPRs would spill 96)
+template <typename T>
+constexpr int seq_waves_per_simd() { return sizeof(T) == 8 ? 2 : 2; }
+
 template <typename T, int STORE = 0, int ABL = 0>
-__global__ __launch_bounds__(S_THREADS, 2) void k_seq_rows(const FusedArgs<T> A)
+__global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows(const FusedArgs<T> A)
 {
     using C = cpx<T>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[seq_lds_bytes<T>()];

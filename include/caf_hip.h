@@ -154,6 +154,27 @@ int caf_surface_dev(caf_plan *plan, const void *d_needle, const void *d_haystack
 int caf_plan_timing_begin(caf_plan *plan);
 int caf_plan_timing_end(caf_plan *plan, double *kernel_ms_total, uint64_t *launches);
 
+/* ---- streaming (BASELINE configs[4]) ----------------------------------------------
+ * Back-to-back surfaces from host memory: `nslots` (>= 2) independent slots, each with
+ * pinned host staging for `batch` (needle, haystack) pairs, its own device buffers, its
+ * own HIP stream and ONE captured hipGraph {H2D needle, H2D haystack, haystack spectrum,
+ * row kernel, find_peak, D2H of the row peaks + caf_peak records}.  While slot k computes,
+ * the caller fills slot k+1's pinned buffers and submits it: its H2D overlaps slot k's
+ * kernels.  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
+ * only (tau, f) + per-row peaks come back, as SURVEY.md section 8d prescribes. */
+typedef struct caf_stream caf_stream;
+int caf_stream_create(caf_plan *plan, size_t batch, int nslots, int want_surface, caf_stream **out);
+int caf_stream_destroy(caf_stream *st);
+/* Pinned host buffers of a slot: [batch][n] complex each (dtype of the plan). */
+int caf_stream_host_buffers(caf_stream *st, int slot, void **needle, void **haystack);
+/* Replay the slot's graph on the slot's stream (asynchronous). */
+int caf_stream_submit(caf_stream *st, int slot);
+/* Block until the slot's last submit finished; copies out `batch` caf_peak records and,
+ * if non-NULL, batch*rows row indices / values (value type of the plan's dtype). */
+int caf_stream_wait(caf_stream *st, int slot, caf_peak *peaks, uint64_t *row_idx, void *row_val);
+/* Device address of the slot's surface slab ([batch][rows][2n]) or NULL. */
+void *caf_stream_surface(caf_stream *st, int slot);
+
 #ifdef __cplusplus
 }
 #endif
