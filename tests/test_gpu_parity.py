@@ -344,3 +344,23 @@ def test_streaming_double_buffer(eng, oracle, golden, manifest):
     finally:
         st.close()
         plan.close()
+
+
+# ------------------------------------------------------------ configs[3] shape --
+def test_L65536_c64_generic_path_rows(eng, oracle):
+    """BASELINE configs[3] geometry (n = 32768 -> L = 65536, complex64) on a few Doppler
+    rows: the generic HBM-pass path against the f64 oracle, tolerance 1e-3 of max, and the
+    synthetic pair's known (lag, Doppler) recovered."""
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.synth import make_pair
+    n = 32768
+    s0, s1, lag, fo = make_pair(n=n, seed=77, lag=173, foffset=12.0, dtype=np.complex64)
+    fr = np.array([11.0, 11.5, 12.0, 12.5, 13.0])
+    plan = eng.plan(n, fr, FS, dtype="c64")
+    assert plan.path == "generic"
+    plan.close()
+    surf, ridx, rval, peak = eng.surface_arrays(s0, s1, fr, FS, dtype="c64")
+    osurf, oidx, oval = oracle.np_caf_surface(s0.astype(np.complex128), s1.astype(np.complex128), fr, FS)
+    assert surf.shape == (5, 65536)
+    assert np.max(np.abs(surf - osurf)) <= TOL32 * osurf.max()
+    assert (peak.freq, peak.idx) == (12.0, lag) == oracle.np_find_peak(fr, oidx, oval)
