@@ -398,7 +398,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
     if (!p) return "";
     const bool f64 = p->dtype == CAF_C128;
     if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
-    if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0>" : "caf::k_seq_rows<float, 0, 0>";
+    if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0, 15>" : "caf::k_seq_rows<float, 0, 0, 15>";
     return f64 ? "caf::k_fused_rows<double, false>" : "caf::k_fused_rows<float, false>";
 }
 
@@ -500,9 +500,10 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
         case 1: k_seq_rows<T, 1><<<grid, S_THREADS, 0, c->stream>>>(a); break;
         case 2: k_seq_rows<T, 2><<<grid, S_THREADS, 0, c->stream>>>(a); break;
         case 3: k_seq_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a); break;
-        case 11: k_seq_rows<T, 0, 1><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // no LDS
-        case 12: k_seq_rows<T, 0, 2><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // no global loads
-        case 13: k_seq_rows<T, 3, 3><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // VALU only
+        case 11: k_seq_rows<T, 0, 1, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // no LDS
+        case 12: k_seq_rows<T, 0, 2, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // no global loads
+        case 13: k_seq_rows<T, 3, 3, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // VALU only
+        case 20: k_seq_rows<T, 0, 0, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;   // no software pipelining
         default: k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;
         }
     } else {

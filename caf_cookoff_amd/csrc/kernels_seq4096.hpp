@@ -90,28 +90,48 @@ __device__ __forceinline__ void keep(cpx<T> &x)
 }
 #define LDS_W(expr_addr, val) do { if constexpr (!(ABL & 1)) { expr_addr = (val); } else { C tmp__ = (val); keep(tmp__); v[k & 15] = tmp__; } } while (0)
 
-template <typename T, int CH, int ABL = 0>
-__device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], const __amdgpu_buffer_rsrc_t rs_sig,
+// PF (software pipelining of the input loads; each bit moves one group of loads earlier):
+//   1: even chain - haystack-spectrum loads issued right after the mixer
+//   2: odd chain  - needle samples loaded during the even chain's last pass
+//   4: odd chain  - haystack-spectrum loads issued before pass 3
+//   8: even chain - the NEXT row's needle samples loaded while the epilogue retires registers
+template <typename T>
+__device__ __forceinline__ void load_samples(cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t rs_sig, const SeqLane &L)
+{
+    using C = cpx<T>;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        a[q] = bload(rs_sig, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * q * sizeof(C)), (C *)nullptr);
+}
+
+template <typename T, int CH, int ABL = 0, int PF = 0>
+__device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t rs_sig,
                                           const __amdgpu_buffer_rsrc_t rs_spec, const cpx<T> *ph,
                                           const cpx<T> cfac, const TwSet<T> &tw, const cpx<T> *twB,
                                           cpx<T> *Lc, const SeqLane &L)
 {
     using C = cpx<T>;
-    const unsigned voff_sig = (unsigned)(L.t * sizeof(C));
     const unsigned voff_spec = (unsigned)((CH * 4096 + L.t) * sizeof(C));
+    constexpr bool A_PRELOADED = (CH == 0 && (PF & 8)) || (CH == 1 && (PF & 2));
+    constexpr bool H_EARLY = (CH == 0 && (PF & 1));
+    constexpr bool H_MID = (CH == 1 && (PF & 4));
+    C h[16];
     // ---- mixer (mod.rs:46-65) fused into the first butterfly's operands -----------------
     {
-        C a[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if constexpr (ABL & 2) { a[q] = C{T(q + 1), T(L.t)}; keep(a[q]); }
-            else a[q] = bload(rs_sig, voff_sig, (unsigned)(256 * q * sizeof(C)), (C *)nullptr);
         }
+        if constexpr (!(ABL & 2) && !A_PRELOADED) load_samples(a, rs_sig, L);
         C pb = cmul(ph[L.lo4], ph[16 + L.hi4]);
         if (CH) pb = cmul(pb, cfac);
         const C *ps = ph + 32 + CH * 16;
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = conj(cmul(cmul(a[q], pb), ps[q]));
+    }
+    if constexpr (H_EARLY) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
     }
     // ---- forward (DIF) ------------------------------------------------------------------
     if constexpr (ABL & 1) {
@@ -131,12 +151,17 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], const __amdgpu_buffer
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = Lc[L.pC + k];
     }
+    if constexpr (H_MID) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
+    }
     dft16(v);
     // ---- spectrum product (xcor_rustfft.rs:64-73) ------------------------------------------
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         C hk;
         if constexpr (ABL & 2) { hk = C{T(1), T(k)}; keep(hk); }
+        else if constexpr (H_EARLY || H_MID) hk = h[k];
         else hk = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
         v[k] = cmul(v[k], hk);
     }
@@ -163,6 +188,8 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], const __amdgpu_buffer
         for (int k = 0; k < 16; ++k) v[k] = Lc[L.pA + k * F_BLK];
         __syncthreads();  // all LDS reads of this chain done: the next chain may write
     }
+    // the odd chain reads the same needle samples: fetch them under the last butterfly
+    if constexpr (CH == 0 && (PF & 2) && !(ABL & 2)) load_samples(a, rs_sig, L);
     apply_twA(v, tw);
     dft16(v);
 }
@@ -190,7 +217,7 @@ __device__ constexpr double W32S16[16] = {0.0, 0.1950903220161282678482848684770
 template <typename T>
 constexpr int seq_waves_per_simd() { return sizeof(T) == 8 ? 2 : 2; }
 
-template <typename T, int STORE = 0, int ABL = 0>
+template <typename T, int STORE = 0, int ABL = 0, int PF = 15>
 __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows(const FusedArgs<T> A)
 {
     using C = cpx<T>;
@@ -215,16 +242,25 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
     const bool odd = L.lane & 1;
     __syncthreads();
 
+    C a[16];
+    if constexpr (PF & 8) {
+        const int gc = (int)blockIdx.x < A.total ? (int)blockIdx.x : A.total - 1;
+        load_samples(a, __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0,
+                                                          F_N * (int)sizeof(C), 0x00020000), L);
+    }
     for (int g = blockIdx.x; g < A.total; g += gridDim.x) {
         const int b = g / A.rows, r = g - b * A.rows;
         const C *ph = A.phasor + (size_t)r * 64;
         const __amdgpu_buffer_rsrc_t rs_sig =
             __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)b * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
+        const int gn = g + (int)gridDim.x, gc = gn < A.total ? gn : A.total - 1;  // clamped: a[] always redefined
+        const __amdgpu_buffer_rsrc_t rs_sig_next = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.spec + (size_t)b * (2 * 16 * 256)), 0, 2 * 16 * 256 * (int)sizeof(C), 0x00020000);
         C e[16], o[16];
-        seq_chain<T, 0, ABL>(e, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L);
-        seq_chain<T, 1, ABL>(o, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L);
+        seq_chain<T, 0, ABL, PF>(e, a, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L);
+        seq_chain<T, 1, ABL, PF>(o, a, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L);
 
         // ---- last radix-2 stage (in registers) + |.|^2 + argmax + 16-B write-through stores --
         T bv_lo = T(0), bv_hi = T(0);
@@ -244,6 +280,8 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
                 mhi[u] = norm_sqr(e[i] - z);
                 if (mlo[u] > bv_lo) { bv_lo = mlo[u]; bi_lo = i; }
                 if (mhi[u] > bv_hi) { bv_hi = mhi[u]; bi_hi = i; }
+                if constexpr (PF & 8)  // e[i], o[i] are dead: their registers take the next row's sample
+                    a[i] = bload(rs_sig_next, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * i * sizeof(C)), (C *)nullptr);
             }
             const T slo = dpp_xor1<T>(odd ? mlo[0] : mlo[1]);
             const T shi = dpp_xor1<T>(odd ? mhi[0] : mhi[1]);
