@@ -15,6 +15,7 @@
 #include "../../include/caf_hip.h"
 #include "kernels_fused4096.hpp"
 #include "kernels_seq4096.hpp"
+#include "kernels_r8_4096.hpp"
 #include "kernels_generic.hpp"
 
 using namespace caf;
@@ -119,7 +120,7 @@ static int build_fused_tables(caf_ctx *c, int dt)
 {
     if (c->tw4096[dt]) return CAF_OK;
     HIPCHK(hipMalloc(&c->tw4096[dt], 4096 * sizeof(cpx<T>)));
-    HIPCHK(hipMalloc(&c->th[dt], 256 * sizeof(cpx<T>)));
+    HIPCHK(hipMalloc(&c->th[dt], 512 * sizeof(cpx<T>)));
     k_fused_tables<T><<<16, 256, 0, c->stream>>>((cpx<T> *)c->tw4096[dt], (cpx<T> *)c->th[dt]);
     KCHK();
     return CAF_OK;
@@ -319,8 +320,12 @@ static int plan_build_tables(caf_plan *p)
         const size_t nr = p->rows + 1;  // +1: the f = 0 row for the haystack transform
         HIPCHK(hipMalloc(&p->d_phasor, nr * 64 * sizeof(cpx<T>)));
         const size_t threads = nr * 64;
-        k_fused_phasors<T><<<(unsigned)((threads + 255) / 256), 256, 0, c->stream>>>(
-            p->d_ph, (int)p->rows, (cpx<T> *)p->d_phasor);
+        if (p->variant == 2)
+            k_r8_phasors<T><<<(unsigned)((threads + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows,
+                                                                                       (cpx<T> *)p->d_phasor);
+        else
+            k_fused_phasors<T><<<(unsigned)((threads + 255) / 256), 256, 0, c->stream>>>(
+                p->d_ph, (int)p->rows, (cpx<T> *)p->d_phasor);
         KCHK();
     } else {
         if ((rc = get_generic_tw<T>(c, p->L, dt, &p->d_tw))) return rc;
@@ -399,6 +404,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
     const bool f64 = p->dtype == CAF_C128;
     if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
     if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0, 15>" : "caf::k_seq_rows<float, 0, 0, 15>";
+    if (p->variant == 2) return f64 ? "caf::k_r8_rows<double, 0>" : "caf::k_r8_rows<float, 0>";
     return f64 ? "caf::k_fused_rows<double, false>" : "caf::k_fused_rows<float, false>";
 }
 
@@ -449,14 +455,6 @@ extern "C" int caf_debug_set_stamps(caf_plan *p, void *d_buf)
     return CAF_OK;
 }
 
-// Internal: choose the row-kernel variant of a fused plan (0 sequential-chain, 1 lane-half).
-extern "C" int caf_debug_set_variant(caf_plan *p, int variant)
-{
-    if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
-    p->variant = variant;
-    return CAF_OK;
-}
-
 // ------------------------------------------------------------ surface (dev) --
 template <typename T>
 static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch,
@@ -477,8 +475,11 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     // xcor_rustfft.rs:58-59)
     a.sig = (const cpx<T> *)d_hay;
     a.total = (int)batch;
-    k_fused_prepare<T><<<(unsigned)(batch < (size_t)c->cu_count ? batch : (size_t)c->cu_count), F_THREADS, 0,
-                         c->stream>>>(a);
+    const unsigned prep_grid = (unsigned)(batch < (size_t)c->cu_count ? batch : (size_t)c->cu_count);
+    if (p->variant == 2)
+        k_r8_prepare<T><<<prep_grid, R_THREADS, 0, c->stream>>>(a);
+    else
+        k_fused_prepare<T><<<prep_grid, F_THREADS, 0, c->stream>>>(a);
     KCHK();
     const size_t total = batch * p->rows;
     if (total == 0) return CAF_OK;
@@ -488,7 +489,15 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     a.row_idx = d_ridx;
     a.row_val = (T *)d_rval;
     if ((rc = timing_mark(p))) return rc;
-    if (p->variant == 0 && !p->dbg) {
+    if (p->variant == 2) {
+        const size_t cap = (size_t)c->cu_count * 2;
+        const unsigned grid = (unsigned)(total < cap ? total : cap);
+        static const int r8_nostore = getenv("CAF_STORE_MODE") ? atoi(getenv("CAF_STORE_MODE")) == 3 : 0;
+        if (r8_nostore)
+            k_r8_rows<T, 3><<<grid, R_THREADS, 0, c->stream>>>(a);
+        else
+            k_r8_rows<T, 0><<<grid, R_THREADS, 0, c->stream>>>(a);
+    } else if (p->variant == 0 && !p->dbg) {
         size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
         if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();  // VGPR-limited
         static const int wg_per_cu_env = getenv("CAF_WG_PER_CU") ? atoi(getenv("CAF_WG_PER_CU")) : 0;  // measurement only

@@ -40,7 +40,7 @@ constexpr int F_COLS = 256;     // butterfly columns per chain
 
 // Row-independent tables (built once per context by k_fused_tables):
 //   tw4096[m] = e^{+2*pi*i*m/4096}, m < 4096
-//   th[t]     = e^{+2*pi*i*t/8192}, t < 256
+//   th[t]     = e^{+2*pi*i*t/8192}, t < 512
 template <typename T>
 struct FusedTables {
     const cpx<T> *tw4096;
@@ -52,7 +52,7 @@ __global__ void k_fused_tables(cpx<T> *__restrict__ tw4096, cpx<T> *__restrict__
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 4096) tw4096[i] = cispi_f64<T>(2.0 * (double)i / 4096.0);
-    if (i < 256) th[i] = cispi_f64<T>(2.0 * (double)i / 8192.0);
+    if (i < 512) th[i] = cispi_f64<T>(2.0 * (double)i / 8192.0);
 }
 
 // Per-row phasor table of a plan: 64 entries per row (1 KiB f64),
