@@ -23,6 +23,8 @@ CAF_ERR_STATE = 6
 
 CAF_C128 = 0
 CAF_C64 = 1
+CAF_VIEW_GO = 1
+CAF_VIEW_PYTHON = 2
 
 
 class CafPeak(ctypes.Structure):
@@ -70,6 +72,7 @@ SYMBOLS = [
     ("caf_surface_dev", _int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     ("caf_plan_timing_begin", _int, [_vp]),
     ("caf_plan_timing_end", _int, [_vp, _dp, _up]),
+    ("caf_surface_view", _int, [_vp, _int, _vp, _sz, _sz, _int, _vp]),
     ("caf_stream_create", _int, [_vp, _sz, _int, _int, ctypes.POINTER(_vp)]),
     ("caf_stream_destroy", _int, [_vp]),
     ("caf_stream_host_buffers", _int, [_vp, _int, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),

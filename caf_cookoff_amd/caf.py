@@ -164,6 +164,38 @@ class Engine:
         check(self.lib.caf_find_peak(self._h, _dptr(fr), _uptr(ri), _dptr(rv), F, ctypes.byref(peak)))
         return float(peak.freq), int(peak.idx)
 
+    # -- views in the Go / Python implementations' conventions -----
+    def surface_view(self, surface: np.ndarray, view: str) -> np.ndarray:
+        """``view='go'``: caf_go amb_surf (2n lags, |.|, lag = n - k, caf.go:95-116, main.go:35);
+        ``view='python'``: caf_python amb_surf (n lags of scipy 'same', |.|, tau = n/2 - i,
+        caf.py:15-18,145)."""
+        surf = np.ascontiguousarray(surface)
+        rows, L = surf.shape
+        n = L // 2
+        code = {"go": _lib.CAF_VIEW_GO, "python": _lib.CAF_VIEW_PYTHON}[view]
+        dt = CAF_C128 if surf.dtype == np.float64 else CAF_C64
+        out = np.empty((rows, L if view == "go" else n), dtype=surf.dtype)
+        check(self.lib.caf_surface_view(self._h, dt, ctypes.c_void_p(surf.ctypes.data), rows, n, code,
+                                        ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    # -- coarse -> fine Doppler search (SURVEY.md 8f.4) -----------------------------
+    def refine_peak(self, needle, haystack, fs: int, coarse_freqs, fine_step: float, dtype: str = "c128"):
+        """Coarse grid first, then a fine grid of ``fine_step`` spanning one coarse bin either
+        side of the coarse peak (the KAT grids of test.rs:174,212 are such fine grids).
+        Returns ((coarse_freq, coarse_idx), (fine_freq, fine_idx), fine_freqs)."""
+        cf = np.ascontiguousarray(coarse_freqs, dtype=np.float64)
+        _, _, _, pk = self.surface_arrays(needle, haystack, cf, fs, want_surface=False, dtype=dtype)
+        if pk.row < 0:
+            return (0.0, 0), (0.0, 0), np.array([])
+        r = int(pk.row)
+        lo = cf[r - 1] if r > 0 else cf[r] - (cf[1] - cf[0] if len(cf) > 1 else fine_step)
+        hi = cf[r + 1] if r + 1 < len(cf) else cf[r] + (cf[-1] - cf[-2] if len(cf) > 1 else fine_step)
+        k0, k1 = int(round(lo / fine_step)), int(round(hi / fine_step))
+        ff = np.array([k * fine_step for k in range(k0, k1 + 1)], dtype=np.float64)
+        _, _, _, pf = self.surface_arrays(needle, haystack, ff, fs, want_surface=False, dtype=dtype)
+        return (float(pk.freq), int(pk.idx)), (float(pf.freq), int(pf.idx)), ff
+
     # -- device-resident plans ----------------------------------------------------
     def plan(self, n: int, freqs_hz, fs: int, dtype: str = "c128", row_begin: int = 0,
              row_end: Optional[int] = None) -> "Plan":

@@ -703,6 +703,38 @@ extern "C" int caf_find_peak(caf_ctx *c, const double *freqs, const uint64_t *ro
     return CAF_OK;
 }
 
+// ------------------------------------------------------------------- views --
+template <typename T>
+static int view_impl(caf_ctx *c, const T *surface, size_t rows, size_t n, int view, T *out)
+{
+    const size_t L = 2 * n, width = view == CAF_VIEW_GO ? L : n, off = view == CAF_VIEW_GO ? n : n / 2;
+    int rc;
+    if ((rc = c->io_surface.ensure(rows * L * sizeof(T)))) return rc;
+    if ((rc = c->io_a.ensure(rows * width * sizeof(T)))) return rc;
+    HIPCHK(hipMemcpyAsync(c->io_surface.p, surface, rows * L * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    for (size_t r0 = 0; r0 < rows; r0 += 65535) {
+        const size_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        k_view<T><<<dim3((unsigned)((width + 255) / 256), (unsigned)nr), 256, 0, c->stream>>>(
+            (const T *)c->io_surface.p + r0 * L, L, width, off, (T *)c->io_a.p + r0 * width);
+    }
+    KCHK();
+    HIPCHK(hipMemcpyAsync(out, c->io_a.p, rows * width * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CAF_OK;
+}
+
+extern "C" int caf_surface_view(caf_ctx *c, int dtype, const void *surface, size_t rows, size_t n, int view, void *out)
+{
+    if (!c || !out || (!surface && rows)) return fail(CAF_ERR_BAD_ARG, "caf_surface_view: NULL argument");
+    if (view != CAF_VIEW_GO && view != CAF_VIEW_PYTHON) return fail(CAF_ERR_BAD_ARG, "caf_surface_view: bad view %d", view);
+    if (dtype != CAF_C128 && dtype != CAF_C64) return fail(CAF_ERR_BAD_ARG, "caf_surface_view: bad dtype %d", dtype);
+    if (n == 0) return fail(CAF_ERR_LENGTH, "caf_surface_view: n == 0");
+    if (rows == 0) return CAF_OK;
+    HIPCHK(hipSetDevice(c->device));
+    return dtype == CAF_C128 ? view_impl<double>(c, (const double *)surface, rows, n, view, (double *)out)
+                             : view_impl<float>(c, (const float *)surface, rows, n, view, (float *)out);
+}
+
 // --------------------------------------------------------------- streaming --
 struct StreamSlot {
     hipStream_t stream = nullptr;

@@ -168,4 +168,16 @@ __global__ __launch_bounds__(256) void k_peak(const double *__restrict__ freqs,
     }
 }
 
+// Go / Python flavoured view of a |.|^2 surface: out[r][i] = sqrt(surf[r][(off - i) mod L]),
+// width = L (Go, off = n) or n (Python 'same', off = n/2).
+template <typename T>
+__global__ void k_view(const T *__restrict__ surf, size_t L, size_t width, size_t off, T *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t r = blockIdx.y;
+    if (i >= width) return;
+    const size_t src = (off + L - (i % L)) % L;
+    out[r * width + i] = sqrt(surf[r * L + src]);
+}
+
 }  // namespace caf

@@ -154,6 +154,18 @@ int caf_surface_dev(caf_plan *plan, const void *d_needle, const void *d_haystack
 int caf_plan_timing_begin(caf_plan *plan);
 int caf_plan_timing_end(caf_plan *plan, double *kernel_ms_total, uint64_t *launches);
 
+/* ---- views of a surface in the other cook-off implementations' conventions ----------
+ * (cheap epilogues over a |.|^2 surface already in memory)
+ *   CAF_VIEW_GO     : caf_go/caf.go:95-116 + main.go:35 -- 2n lags, magnitude (not squared),
+ *                     needle padded at the end / haystack at the front:
+ *                     out[r][k] = sqrt(surface[r][(n - k) mod 2n]),  lag = n - k
+ *   CAF_VIEW_PYTHON : caf_python/caf.py:15-18,145 -- scipy correlate(mode='same'): n lags,
+ *                     magnitude, reversed lag axis: out[r][i] = sqrt(surface[r][(n/2 - i) mod 2n]),
+ *                     tau = n/2 - i
+ * Host pointers; `surface` is rows x 2n of the dtype's real type, `out` rows x (2n | n). */
+enum caf_view { CAF_VIEW_GO = 1, CAF_VIEW_PYTHON = 2 };
+int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, size_t n, int view, void *out);
+
 /* ---- streaming (BASELINE configs[4]) ----------------------------------------------
  * Back-to-back surfaces from host memory: `nslots` (>= 2) independent slots, each with
  * pinned host staging for `batch` (needle, haystack) pairs, its own device buffers, its

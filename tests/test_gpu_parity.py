@@ -364,3 +364,54 @@ def test_L65536_c64_generic_path_rows(eng, oracle):
     assert surf.shape == (5, 65536)
     assert np.max(np.abs(surf - osurf)) <= TOL32 * osurf.max()
     assert (peak.freq, peak.idx) == (12.0, lag) == oracle.np_find_peak(fr, oidx, oval)
+
+
+# ------------------------------------------------- "next" rows of SURVEY.md 8(f) --
+def test_go_and_python_views(eng, oracle):
+    """The other cook-off implementations' conventions as views of the same surface,
+    checked against direct restatements of caf_go/caf.go:95-116 and caf_python/caf.py:15-18."""
+    from scipy import signal
+    nd, hs = _pair(oracle, 4)
+    n = len(nd)
+    fr = np.array([82.5, 83.0, 83.5])
+    surf, ridx, rval, peak = eng.surface_arrays(nd, hs, fr, FS)
+    go = eng.surface_view(surf, "go")
+    py = eng.surface_view(surf, "python")
+    assert go.shape == (3, 2 * n) and py.shape == (3, n)
+    z = np.zeros(n, dtype=np.complex128)
+    for r, f in enumerate(fr):
+        shifted = nd * np.exp(2j * np.pi * f * np.arange(n) / FS)          # apply_fdoa (caf.go:118-126)
+        corr = np.fft.ifft(np.fft.fft(np.concatenate([shifted, z])) *
+                           np.conj(np.fft.fft(np.concatenate([z, hs]))))   # xcor (caf.go:95-116)
+        assert np.max(np.abs(go[r] - np.abs(corr))) <= 1e-9 * np.abs(corr).max()
+        same = np.abs(signal.correlate(shifted, hs, mode="same", method="fft"))  # caf.py:15-18
+        assert np.max(np.abs(py[r] - same)) <= 1e-9 * same.max()
+    # main.go:35 and caf.py:145 recover the same (tau, f) as find_peak
+    fdx, tdx = np.unravel_index(np.argmax(go), go.shape)
+    assert (n - tdx, fr[fdx]) == (peak.idx, peak.freq) == (70, 83.0)
+    fdx, tmax = np.unravel_index(np.argmax(py), py.shape)
+    assert (n // 2 - tmax, fr[fdx]) == (70, 83.0)
+
+
+def test_refine_peak_coarse_to_fine(eng, oracle):
+    """Coarse 1 Hz grid then the fine grids of the reference's KATs (test.rs:174,212)."""
+    for k, coarse, fine, want in ((2, (25.0, 40.0, 1.0), 0.05, (32.15, 169)), (4, (70.0, 100.0, 1.0), 0.1, (82.9, 70))):
+        nd, hs = _pair(oracle, k)
+        cf = oracle.gen_float_shifts(*coarse)
+        (cfq, cidx), (ffq, fidx), ff = eng.refine_peak(nd, hs, FS, cf, fine)
+        assert cidx == want[1] and abs(cfq - want[0]) <= 0.5
+        assert fidx == want[1] and abs(ffq - want[0]) < 1e-9
+
+
+def test_cli_demo(tmp_path):
+    import subprocess, sys
+    from conftest import ROOT
+    dump = tmp_path / "surf.bin"
+    r = subprocess.run([sys.executable, "-m", "caf_cookoff_amd", str(DATA / "chirp_0_raw.c64"),
+                        str(DATA / "chirp_0_T+202samp_F+69.25Hz.c64"), "--dump-surf", str(dump), "--view", "go"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == ["Frequency offset: 69.0Hz", "Time offset: 202 samples (4.208ms)"]  # main.rs:29-31
+    surf = np.fromfile(dump, dtype="<f8").reshape(400, 8192)
+    fdx, tdx = np.unravel_index(np.argmax(surf), surf.shape)
+    assert 4096 - tdx == 202  # main.go:35
