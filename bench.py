@@ -126,11 +126,19 @@ def main():
             sys.exit(2)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists)")
+    # Rehearsal mode for a one-GPU box (never used by the driver): every rank shares cuda:0 and
+    # the peak reduction runs over gloo on CPU copies; everything else is the N>1 code path.
+    rehearse = os.environ.get("CAF_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     eng = caf.Engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -160,6 +168,10 @@ def main():
         if world == 1:
             return None
         # find_peak across the row shards: RCCL all-reduce(max) + all-reduce(min) on 8 B per surface
+        if rehearse:
+            pk_c = peak.cpu()
+            pk_ci = pk_c.view(torch.int64)
+            return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2])
         return reduce_global_peak(peak[:, 0], peak_i[:, 3], peak_i[:, 2])
 
     def sync_all():
@@ -167,6 +179,12 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def allreduce_max_time(seconds: float) -> float:
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if rehearse else dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         out = step()
@@ -201,10 +219,7 @@ def main():
         torch.cuda.synchronize()
     el = time.perf_counter() - t0
     kern_ms_total, launches = plan.timing_end()
-    t = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
+    el = allreduce_max_time(el)
 
     if rank == 0:
         value = nsurf * K / el
