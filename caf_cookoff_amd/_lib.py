@@ -55,6 +55,7 @@ SYMBOLS = [
     ("caf_ctx_create", _int, [_int, ctypes.POINTER(_vp)]),
     ("caf_ctx_destroy", _int, [_vp]),
     ("caf_ctx_set_stream", _int, [_vp, _vp]),
+    ("caf_ctx_reset_stream", _int, [_vp]),
     ("caf_ctx_synchronize", _int, [_vp]),
     ("caf_ctx_device_info", _int, [_vp, ctypes.POINTER(_int), ctypes.c_char_p, _sz]),
     ("caf_apply_freq_shift_c128", _int, [_vp, _dp, _sz, ctypes.c_double, _u32, _dp]),

@@ -71,7 +71,12 @@ class Engine:
 
     # -- plumbing ---------------------------------------------------------------
     def set_stream(self, hip_stream: Optional[int]):
-        check(self.lib.caf_ctx_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
+        """Run on the given hipStream_t handle (0 = HIP's null stream = torch's default
+        stream); ``None`` goes back to the context's private stream."""
+        if hip_stream is None:
+            check(self.lib.caf_ctx_reset_stream(self._h))
+        else:
+            check(self.lib.caf_ctx_set_stream(self._h, ctypes.c_void_p(int(hip_stream))))
 
     def synchronize(self):
         check(self.lib.caf_ctx_synchronize(self._h))

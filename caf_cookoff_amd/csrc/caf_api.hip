@@ -212,8 +212,18 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
 extern "C" int caf_ctx_set_stream(caf_ctx *c, void *hip_stream)
 {
     if (!c) return fail(CAF_ERR_BAD_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;  // NULL == the null stream
+    return CAF_OK;
+}
+
+extern "C" int caf_ctx_reset_stream(caf_ctx *c)
+{
+    if (!c) return fail(CAF_ERR_BAD_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
     return CAF_OK;
 }
 
@@ -497,6 +507,12 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
             k_r8_rows<T, 3><<<grid, R_THREADS, 0, c->stream>>>(a);
         else
             k_r8_rows<T, 0><<<grid, R_THREADS, 0, c->stream>>>(a);
+    } else if (p->variant == 0 && p->dbg) {
+        size_t per_cu = 2;
+        static const int wg_env = getenv("CAF_WG_PER_CU") ? atoi(getenv("CAF_WG_PER_CU")) : 0;
+        if (wg_env > 0) per_cu = (size_t)wg_env;
+        const size_t cap = (size_t)c->cu_count * per_cu;
+        k_seq_rows<T, 0, 8, 15><<<(unsigned)(total < cap ? total : cap), S_THREADS, 0, c->stream>>>(a);
     } else if (p->variant == 0 && !p->dbg) {
         size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
         if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();  // VGPR-limited

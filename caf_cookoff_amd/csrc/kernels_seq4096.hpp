@@ -104,12 +104,22 @@ __device__ __forceinline__ void load_samples(cpx<T> (&a)[16], const __amdgpu_buf
         a[q] = bload(rs_sig, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * q * sizeof(C)), (C *)nullptr);
 }
 
+// ABL bit 3: s_memtime stamps (diagnostic build, tools/stamps_seq.py)
+constexpr int S_NSTAMP = 24;
+#define SEQ_STAMP(i)                                                                             \
+    if constexpr (ABL & 8) {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[(i) + CH * 11])::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+
 template <typename T, int CH, int ABL = 0, int PF = 0>
 __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t rs_sig,
                                           const __amdgpu_buffer_rsrc_t rs_spec, const cpx<T> *ph,
                                           const cpx<T> cfac, const TwSet<T> &tw, const cpx<T> *twB,
-                                          cpx<T> *Lc, const SeqLane &L)
+                                          cpx<T> *Lc, const SeqLane &L, unsigned long long (&st)[S_NSTAMP])
 {
+    SEQ_STAMP(0);
     using C = cpx<T>;
     const unsigned voff_spec = (unsigned)((CH * 4096 + L.t) * sizeof(C));
     constexpr bool A_PRELOADED = (CH == 0 && (PF & 8)) || (CH == 1 && (PF & 2));
@@ -133,6 +143,7 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
 #pragma unroll
         for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
     }
+    SEQ_STAMP(1);  // mixer done
     // ---- forward (DIF) ------------------------------------------------------------------
     if constexpr (ABL & 1) {
         dft16(v);
@@ -143,10 +154,13 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
         for (int k = 1; k < 16; ++k) { v[k] = cmul(v[k], tw.w3); keep(v[k]); }
     } else {
         dft16_sink(v, [&](int k, C x) { Lc[L.pA + k * F_BLK] = twA_k(x, k, tw); });
+        SEQ_STAMP(2);  // DFT#1 + twA + ex1 writes retired
         __syncthreads();
+        SEQ_STAMP(3);  // barrier ex1
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
         dft16_sink(v, [&](int k, C x) { Lc[L.pB + 17 * k] = k ? cmul(x, twB[16 * k]) : x; });
+        SEQ_STAMP(4);  // ex1 read + DFT#2 + twB + ex2 writes
         wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = Lc[L.pC + k];
@@ -156,6 +170,7 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
         for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
     }
     dft16(v);
+    SEQ_STAMP(5);  // ex2 read + DFT#3
     // ---- spectrum product (xcor_rustfft.rs:64-73) ------------------------------------------
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -176,6 +191,7 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
     } else {
         wave_lds_fence();
         dft16_sink(v, [&](int k, C x) { Lc[L.pC + k] = x; });
+        SEQ_STAMP(6);  // H mul + DFT#4 + ex3 writes
         wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
@@ -183,15 +199,19 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
         for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twB[16 * k]);
         wave_lds_fence();
         dft16_sink(v, [&](int k, C x) { Lc[L.pB + 17 * k] = x; });
+        SEQ_STAMP(7);  // ex3 read + twB + DFT#5 + ex4 writes
         __syncthreads();
+        SEQ_STAMP(8);  // barrier ex4
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = Lc[L.pA + k * F_BLK];
         __syncthreads();  // all LDS reads of this chain done: the next chain may write
+        SEQ_STAMP(9);  // ex4 read + barrier
     }
     // the odd chain reads the same needle samples: fetch them under the last butterfly
     if constexpr (CH == 0 && (PF & 2) && !(ABL & 2)) load_samples(a, rs_sig, L);
     apply_twA(v, tw);
     dft16(v);
+    SEQ_STAMP(10);  // twA + DFT#6
 }
 
 // W_32^m2, m2 < 16
@@ -242,6 +262,8 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
     const bool odd = L.lane & 1;
     __syncthreads();
 
+    unsigned long long st[S_NSTAMP] = {};
+    int iter = 0;
     C a[16];
     if constexpr (PF & 8) {
         const int gc = (int)blockIdx.x < A.total ? (int)blockIdx.x : A.total - 1;
@@ -259,8 +281,8 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
         const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.spec + (size_t)b * (2 * 16 * 256)), 0, 2 * 16 * 256 * (int)sizeof(C), 0x00020000);
         C e[16], o[16];
-        seq_chain<T, 0, ABL, PF>(e, a, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L);
-        seq_chain<T, 1, ABL, PF>(o, a, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L);
+        seq_chain<T, 0, ABL, PF>(e, a, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L, st);
+        seq_chain<T, 1, ABL, PF>(o, a, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L, st);
 
         // ---- last radix-2 stage (in registers) + |.|^2 + argmax + 16-B write-through stores --
         T bv_lo = T(0), bv_hi = T(0);
@@ -311,6 +333,15 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
             A.row_val[g] = bv;
         }
         // scratch is rewritten only after the next row's six barriers: no extra barrier needed
+        if constexpr (ABL & 8) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[22])::"memory");
+            if (blockIdx.x == 0 && L.lane == 0 && iter < 32) {
+#pragma unroll
+                for (int i = 0; i < S_NSTAMP; ++i) A.dbg[((size_t)iter * 4 + L.wave) * S_NSTAMP + i] = st[i];
+            }
+            ++iter;
+        }
     }
 }
 

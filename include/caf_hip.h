@@ -73,9 +73,12 @@ int caf_device_count(void);
 /* ---- context ----------------------------------------------------------- */
 int caf_ctx_create(int device_id, caf_ctx **out);
 int caf_ctx_destroy(caf_ctx *ctx);
-/* Run all work of this context on a caller-owned hipStream_t (e.g. torch's
- * current stream).  NULL restores the context's own stream. */
+/* Run all work of this context on a caller-owned hipStream_t, e.g. torch's current
+ * stream.  The handle is used as given: NULL is HIP's null (legacy default) stream, which
+ * is what torch.cuda.current_stream().cuda_stream returns for torch's default stream.
+ * caf_ctx_reset_stream goes back to the context's private non-blocking stream. */
 int caf_ctx_set_stream(caf_ctx *ctx, void *hip_stream);
+int caf_ctx_reset_stream(caf_ctx *ctx);
 int caf_ctx_synchronize(caf_ctx *ctx);
 /* Device facts for reports: CU count and name (buf may be NULL). */
 int caf_ctx_device_info(caf_ctx *ctx, int *cu_count, char *name_buf, size_t name_cap);
