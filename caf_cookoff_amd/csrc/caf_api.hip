@@ -472,12 +472,14 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
 {
     caf_ctx *c = p->ctx;
     int rc;
-    if (!p->spec_override && (rc = p->spec.ensure(batch * 2 * 16 * 256 * sizeof(cpx<T>)))) return rc;
+    const size_t spec_bytes = batch * 2 * 16 * 256 * sizeof(cpx<T>);  // + 256 B: the row-ticket counter
+    if (!p->spec_override && (rc = p->spec.ensure(spec_bytes + 256))) return rc;
     FusedArgs<T> a;
     a.phasor = (const cpx<T> *)p->d_phasor;
     a.tab.tw4096 = (const cpx<T> *)c->tw4096[p->dtype];
     a.tab.th = (const cpx<T> *)c->th[p->dtype];
     a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
+    a.work = (unsigned *)((unsigned char *)a.spec + spec_bytes);
     a.rows = (int)p->rows;
     a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr;
     a.dbg = p->dbg;
@@ -820,7 +822,7 @@ extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want
             s.stream = st->slots[0].stream;
             s.own_stream = false;
         }
-        if (p->fused) SCHK(hipMalloc(&s.d_spec, batch * 2 * 16 * 256 * elem_size(p->dtype)));
+        if (p->fused) SCHK(hipMalloc(&s.d_spec, batch * 2 * 16 * 256 * elem_size(p->dtype) + 256));
         SCHK(hipHostMalloc(&s.h_needle, in_bytes, hipHostMallocDefault));
         SCHK(hipHostMalloc(&s.h_hay, in_bytes, hipHostMallocDefault));
         SCHK(hipHostMalloc(&s.h_peak, batch * sizeof(caf_peak), hipHostMallocDefault));

@@ -224,6 +224,7 @@ struct FusedArgs {
     int rows;               // rows per surface handled by this plan
     int total;              // batch*rows (prepare: batch)
     unsigned long long *dbg;  // DIAG builds only: [iter][wave][F_NSTAMP] s_memtime stamps of workgroup 0
+    unsigned *work;           // row-ticket counter of this launch (zeroed by the prepare kernel)
 };
 
 constexpr int F_NSTAMP = 17;
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(F_THREADS) void k_fused_prepare(const FusedArgs<T> 
     const C th = A.tab.th[L.t];
     const C cfac = L.chain ? conj(th) : C{T(1), T(0)};
     const C *ph = A.phasor + (size_t)A.rows * 64;  // the f = 0 row
+    if (blockIdx.x == 0 && L.tid == 0 && A.work) *A.work = 0u;  // row tickets of the following row kernel
     for (int b = blockIdx.x; b < A.total; b += gridDim.x) {
         const C *sig = A.sig + (size_t)b * F_N;
         const C pb = row_phasor_base(ph, L, cfac);

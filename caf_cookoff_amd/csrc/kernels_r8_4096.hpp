@@ -244,6 +244,7 @@ __global__ __launch_bounds__(R_THREADS, 4) void k_r8_prepare(const FusedArgs<T> 
     const R8Setup<T> S(smem, A, L);
     __syncthreads();
     const C *ph = A.phasor + (size_t)A.rows * 64;  // the f = 0 row
+    if (blockIdx.x == 0 && L.tid == 0 && A.work) *A.work = 0u;
     const T inv = T(1.0 / 8192.0);
     for (int b = blockIdx.x; b < A.total; b += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs_sig =

@@ -21,7 +21,7 @@ namespace caf {
 constexpr int S_THREADS = 256;
 
 template <typename T>
-constexpr size_t seq_lds_bytes() { return (F_CHAIN + 256) * sizeof(cpx<T>) + 64; }
+constexpr size_t seq_lds_bytes() { return (F_CHAIN + 256) * sizeof(cpx<T>) + 64; }  // +64: argmax scratch, next-row word
 
 struct SeqLane {
     int tid, lane, wave, t, hi4, lo4, pA, pB, pC;
@@ -264,24 +264,37 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
 
     unsigned long long st[S_NSTAMP] = {};
     int iter = 0;
+    unsigned long long wg_t0 = 0;
+    if constexpr (ABL & 8) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0)::"memory");
     C a[16];
     if constexpr (PF & 8) {
         const int gc = (int)blockIdx.x < A.total ? (int)blockIdx.x : A.total - 1;
         load_samples(a, __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0,
                                                           F_N * (int)sizeof(C), 0x00020000), L);
     }
-    for (int g = blockIdx.x; g < A.total; g += gridDim.x) {
+    // Rows are handed out dynamically: workgroup i starts with row i, then draws tickets
+    // gridDim + 0, 1, 2 ... from one device-scope counter (zeroed by the prepare kernel that
+    // precedes this launch on the stream).  Identical workgroups finish 25 identical rows up
+    // to 30 % apart (per-CU clock/L2 effects, profiles/r01_v3 notes); with tickets they all end
+    // within one row time.  Tickets are in surface-major order, so at any moment the whole chip
+    // works on 1-2 surfaces and their inputs stay L2-resident, as with static striding.
+    volatile int *const next_row = reinterpret_cast<volatile int *>(scratch + 48);
+    for (int g = blockIdx.x; g < A.total;) {
+        if (L.tid == 0)
+            *next_row = A.work ? (int)gridDim.x + (int)atomicAdd(A.work, 1u) : g + (int)gridDim.x;
         const int b = g / A.rows, r = g - b * A.rows;
         const C *ph = A.phasor + (size_t)r * 64;
         const __amdgpu_buffer_rsrc_t rs_sig =
             __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)b * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
-        const int gn = g + (int)gridDim.x, gc = gn < A.total ? gn : A.total - 1;  // clamped: a[] always redefined
-        const __amdgpu_buffer_rsrc_t rs_sig_next = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.spec + (size_t)b * (2 * 16 * 256)), 0, 2 * 16 * 256 * (int)sizeof(C), 0x00020000);
         C e[16], o[16];
         seq_chain<T, 0, ABL, PF>(e, a, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L, st);
+        // the ticket was stored before the chain's barriers: visible to every wave by now
+        const int gn = __builtin_amdgcn_readfirstlane(*next_row);
+        const int gc = gn < A.total ? gn : A.total - 1;  // clamped: a[] is always redefined
+        const __amdgpu_buffer_rsrc_t rs_sig_next = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
         seq_chain<T, 1, ABL, PF>(o, a, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L, st);
 
         // ---- last radix-2 stage (in registers) + |.|^2 + argmax + 16-B write-through stores --
@@ -341,6 +354,20 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
                 for (int i = 0; i < S_NSTAMP; ++i) A.dbg[((size_t)iter * 4 + L.wave) * S_NSTAMP + i] = st[i];
             }
             ++iter;
+        }
+        g = gn;
+    }
+    if constexpr (ABL & 8) {
+        unsigned long long wg_t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1)::"memory");
+        if (L.tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+            unsigned long long *rec = A.dbg + 32 * 4 * S_NSTAMP + (size_t)blockIdx.x * 4;
+            rec[0] = wg_t0;
+            rec[1] = wg_t1;
+            rec[2] = ((unsigned long long)(xcc & 15u) << 32) | hw;
+            rec[3] = (unsigned long long)iter;
         }
     }
 }

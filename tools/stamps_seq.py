@@ -25,15 +25,30 @@ surf = torch.empty((batch, 400, 8192), dtype=torch.float64, device="cuda")
 ridx = torch.empty((batch, 400), dtype=torch.int64, device="cuda")
 rval = torch.empty((batch, 400), dtype=torch.float64, device="cuda")
 peak = torch.empty((batch, 4), dtype=torch.float64, device="cuda")
-dbg = torch.zeros((32, 4, NST), dtype=torch.int64, device="cuda")
+dbg_all = torch.zeros(32 * 4 * NST + 4 * 1024, dtype=torch.int64, device="cuda")
+dbg = dbg_all[:32 * 4 * NST].view(32, 4, NST)
 lib = caf.load()
 lib.caf_debug_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 args = (nd.data_ptr(), hs.data_ptr(), batch, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(), peak.data_ptr())
 plan.surface_dev(*args)
 torch.cuda.synchronize()
-assert lib.caf_debug_set_stamps(plan._h, ctypes.c_void_p(dbg.data_ptr())) == 0
+assert lib.caf_debug_set_stamps(plan._h, ctypes.c_void_p(dbg_all.data_ptr())) == 0
 plan.surface_dev(*args)
 torch.cuda.synchronize()
+rec = dbg_all[32 * 4 * NST:].view(1024, 4).cpu().numpy()[:512]
+t0, t1 = rec[:, 0].astype(np.float64), rec[:, 1].astype(np.float64)
+base = t0.min()
+dur = t1 - t0
+hw = rec[:, 2]
+cu = ((hw >> 32) & 15) * 256 + ((hw >> 8) & 255)        # xcc | se,sh,cu
+print(f"workgroups: start spread {np.ptp(t0):.0f} ticks, duration min/median/max {dur.min():.0f}/{np.median(dur):.0f}/{dur.max():.0f} "
+      f"ticks, last end - first start {t1.max() - base:.0f}; rows per WG {rec[:, 3].min()}..{rec[:, 3].max()}")
+ucu, cnt = np.unique(cu, return_counts=True)
+print(f"distinct CUs used {len(ucu)}, workgroups per CU histogram {dict(zip(*np.unique(cnt, return_counts=True)))}")
+for c in (1, 2, 3):
+    sel = np.isin(cu, ucu[cnt == c])
+    if sel.any():
+        print(f"  CUs holding {c} WG(s): WG duration median {np.median(dur[sel]):.0f} ticks, mean end {np.mean(t1[sel] - base):.0f}")
 d = dbg.cpu().numpy()[2:20].astype(np.float64)  # [iter][wave][stamp]
 tot = (d[:, :, 22] - d[:, :, 0]).mean()
 print(f"rows sampled {d.shape[0]}; mean cycles per row {tot:.0f} (row period {np.diff(d[:, 0, 0]).mean():.0f})")
