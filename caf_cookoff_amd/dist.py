@@ -7,14 +7,15 @@ state), so there is NO data-path collective: every rank holds the (replicated, 1
 inputs, computes rows [r*F/G, (r+1)*F/G) of every surface in the batch and keeps its
 slab of the surface.  The only exchange is find_peak (mod.rs:31-42):
 
-    gmax = all_reduce(local peak value, MAX)
-    key  = (global_row << 32 | idx)  if local value == gmax and the rank has a peak
-           else INT64_MAX
-    key  = all_reduce(key, MIN)          -> lowest global row among equal peaks wins,
-                                            which is the reference's first-strictly-greater scan
+    every rank contributes (value, key) with key = (global_row << 32 | idx), INT64_MAX if
+    it has no peak; ONE all_gather (16 B per surface per rank) makes all pairs visible and
+    each rank reduces locally: gmax = max value, then the lowest key among the holders of
+    gmax -> lowest global row among equal peaks wins, which is the reference's
+    first-strictly-greater scan.
 
-RCCL has no MAXLOC; two 8-byte-per-surface all-reduces are latency-bound (a few us over
-xGMI) and are issued once per batch, not per surface.
+RCCL has no MAXLOC.  The collective is latency-bound (a few us over xGMI for 16 B x batch
+per rank) and is issued once per batch, not per surface; `method="allreduce"` keeps the
+two-step MAX / MIN-key form (two dependent collectives).
 """
 from __future__ import annotations
 
@@ -40,7 +41,7 @@ def decode_key(key: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def reduce_global_peak(val: torch.Tensor, row: torch.Tensor, idx: torch.Tensor,
-                       group: Optional[dist.ProcessGroup] = None
+                       group: Optional[dist.ProcessGroup] = None, method: str = "allgather"
                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Combine per-rank shard peaks into the global find_peak result.
 
@@ -53,6 +54,21 @@ def reduce_global_peak(val: torch.Tensor, row: torch.Tensor, idx: torch.Tensor,
         has = row >= 0
         return (torch.where(has, val, torch.zeros_like(val)), torch.where(has, row, torch.full_like(row, -1)),
                 torch.where(has, idx, torch.zeros_like(idx)))
+    if method == "allgather":
+        has = row >= 0
+        mine = torch.stack([torch.where(has, val, torch.zeros_like(val)).view(torch.int64),
+                            torch.where(has, encode_key(row, idx), torch.full_like(row, NO_PEAK_KEY, dtype=torch.int64))],
+                           dim=1).contiguous()                                   # [batch, 2] int64 bit patterns
+        world = dist.get_world_size(group)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)  # (the list form also exists on gloo)
+        allp = torch.stack(parts, dim=0)
+        vals = allp[:, :, 0].view(torch.float64)                                  # [world, batch]
+        keys = allp[:, :, 1]
+        gmax = vals.max(dim=0).values
+        keys = torch.where((vals == gmax) & (gmax > 0), keys, torch.full_like(keys, NO_PEAK_KEY))
+        grow, gidx = decode_key(keys.min(dim=0).values)
+        return gmax, grow, gidx
     gmax = torch.where(row >= 0, val, torch.zeros_like(val)).clone()
     dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
     mine = (row >= 0) & (val == gmax) & (gmax > 0)

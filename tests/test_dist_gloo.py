@@ -61,6 +61,8 @@ def _worker(rank, world, port, case, out_q):
             row = torch.tensor([[5, -1, 2, 4], [150, -1, 199, 120], [300, -1, 301, 333]][rank], dtype=torch.int64)
             idx = torch.tensor([[11, 0, 12, 13], [21, 0, 22, 23], [31, 0, 32, 33]][rank], dtype=torch.int64)
             gmax, grow, gidx = reduce_global_peak(val, row, idx)
+            g2, r2, i2 = reduce_global_peak(val, row, idx, method="allreduce")
+            assert torch.equal(gmax, g2) and torch.equal(grow, r2) and torch.equal(gidx, i2)
             out_q.put((rank, gmax.tolist(), grow.tolist(), gidx.tolist()))
     finally:
         dist.destroy_process_group()
