@@ -16,6 +16,7 @@
 #include "kernels_fused4096.hpp"
 #include "kernels_seq4096.hpp"
 #include "kernels_r8_4096.hpp"
+#include "kernels_big65536.hpp"
 #include "kernels_generic.hpp"
 
 using namespace caf;
@@ -72,6 +73,8 @@ struct caf_ctx {
     // row-independent fused tables per dtype
     void *tw4096[2] = {nullptr, nullptr};
     void *th[2] = {nullptr, nullptr};
+    void *bigw256[2] = {nullptr, nullptr};  // tiled65536 path tables
+    void *bigwL[2] = {nullptr, nullptr};
     // generic FFT twiddles per (L, dtype)
     std::map<std::pair<size_t, int>, void *> tw_cache;
     // host-API staging + cached plan
@@ -87,6 +90,8 @@ struct caf_plan {
     uint32_t fs = 0;
     size_t nfreq_total = 0, row_begin = 0, rows = 0;
     bool fused = false;
+    bool big = false;           // n == 32768: four-step tiled path
+    DevBuf bwork, bhwork, bpart_val, bpart_idx;
     double *d_freqs = nullptr;  // this shard's slice
     double *d_ph = nullptr;
     // fused
@@ -199,6 +204,10 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
     for (int d = 0; d < 2; ++d) {
         if (c->tw4096[d]) (void)hipFree(c->tw4096[d]);
         if (c->th[d]) (void)hipFree(c->th[d]);
+    }
+    for (int d = 0; d < 2; ++d) {
+        if (c->bigw256[d]) (void)hipFree(c->bigw256[d]);
+        if (c->bigwL[d]) (void)hipFree(c->bigwL[d]);
     }
     for (auto &kv : c->tw_cache) (void)hipFree(kv.second);
     c->io_needle.release(); c->io_hay.release(); c->io_surface.release();
@@ -325,7 +334,19 @@ static int plan_build_tables(caf_plan *p)
     caf_ctx *c = p->ctx;
     const int dt = p->dtype;
     int rc;
-    if (p->fused) {
+    if (p->big) {
+        if (!c->bigw256[dt]) {
+            HIPCHK(hipMalloc(&c->bigw256[dt], 256 * sizeof(cpx<T>)));
+            HIPCHK(hipMalloc(&c->bigwL[dt], 256 * sizeof(cpx<T>)));
+            k_big_tables<T><<<1, 256, 0, c->stream>>>((cpx<T> *)c->bigw256[dt], (cpx<T> *)c->bigwL[dt]);
+            KCHK();
+        }
+        const size_t nr = p->rows + 1;
+        HIPCHK(hipMalloc(&p->d_phasor, nr * 384 * sizeof(cpx<T>)));
+        k_big_phasors<T><<<(unsigned)((nr * 384 + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows,
+                                                                                   (cpx<T> *)p->d_phasor);
+        KCHK();
+    } else if (p->fused) {
         if ((rc = build_fused_tables<T>(c, dt))) return rc;
         const size_t nr = p->rows + 1;  // +1: the f = 0 row for the haystack transform
         HIPCHK(hipMalloc(&p->d_phasor, nr * 64 * sizeof(cpx<T>)));
@@ -367,6 +388,7 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     p->row_begin = row_begin;
     p->rows = row_end - row_begin;
     p->fused = (n == (size_t)F_N);
+    p->big = (n == (size_t)B_N);
     if (const char *ev = getenv("CAF_ROW_KERNEL")) p->variant = atoi(ev);
     int rc = CAF_OK;
     auto bail = [&](int code) { caf_plan_destroy(p); return code; };
@@ -400,18 +422,23 @@ extern "C" int caf_plan_destroy(caf_plan *p)
     if (p->d_ph) (void)hipFree(p->d_ph);
     if (p->d_phasor) (void)hipFree(p->d_phasor);
     p->spec.release(); p->wx.release(); p->wy.release(); p->hx.release(); p->hy.release();
+    p->bwork.release(); p->bhwork.release(); p->bpart_val.release(); p->bpart_idx.release();
     for (auto ev : p->ev) (void)hipEventDestroy(ev);
     if (p->ctx->cached == p) p->ctx->cached = nullptr;
     delete p;
     return CAF_OK;
 }
 
-extern "C" const char *caf_plan_path(const caf_plan *p) { return !p ? "" : p->fused ? "fused4096" : "generic"; }
+extern "C" const char *caf_plan_path(const caf_plan *p)
+{
+    return !p ? "" : p->fused ? "fused4096" : p->big ? "tiled65536" : "generic";
+}
 extern "C" size_t caf_plan_rows(const caf_plan *p) { return p ? p->rows : 0; }
 extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
 {
     if (!p) return "";
     const bool f64 = p->dtype == CAF_C128;
+    if (p->big) return f64 ? "caf::k_big_rows<double>" : "caf::k_big_rows<float>";
     if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
     if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0, 15>" : "caf::k_seq_rows<float, 0, 0, 15>";
     if (p->variant == 2) return f64 ? "caf::k_r8_rows<double, 0>" : "caf::k_r8_rows<float, 0>";
@@ -547,6 +574,60 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     return CAF_OK;
 }
 
+// n = 32768: four-step tiled path (kernels_big65536.hpp)
+template <typename T>
+static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
+                           uint64_t *d_ridx, void *d_rval)
+{
+    caf_ctx *c = p->ctx;
+    const size_t rows = p->rows, total = batch * rows;
+    int rc;
+    if ((rc = p->bhwork.ensure(batch * B_L * sizeof(cpx<T>)))) return rc;
+    if (!p->spec_override && (rc = p->spec.ensure(batch * B_L * sizeof(cpx<T>)))) return rc;
+    BigArgs<T> a;
+    a.phasor = (const cpx<T> *)p->d_phasor;
+    a.w256 = (const cpx<T> *)c->bigw256[p->dtype];
+    a.wL = (const cpx<T> *)c->bigwL[p->dtype];
+    a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
+    a.rows = (int)rows;
+    a.surface = nullptr; a.part_val = nullptr; a.part_idx = nullptr;
+    // haystack spectrum once per surface
+    a.prepare = 1;
+    a.sig = (const cpx<T> *)d_hay;
+    a.work = (cpx<T> *)p->bhwork.p;
+    for (size_t w0 = 0; w0 < batch; w0 += 32768) {
+        const size_t nw = batch - w0 < 32768 ? batch - w0 : 32768;
+        a.wr0 = (unsigned)w0;
+        k_big_cols_fwd<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
+        k_big_rows<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
+    }
+    KCHK();
+    if (total == 0) return CAF_OK;
+    if ((rc = p->bwork.ensure(total * B_L * sizeof(cpx<T>)))) return rc;
+    if ((rc = p->bpart_val.ensure(total * 16 * sizeof(T)))) return rc;
+    if ((rc = p->bpart_idx.ensure(total * 16 * sizeof(uint32_t)))) return rc;
+    a.prepare = 0;
+    a.sig = (const cpx<T> *)d_needle;
+    a.work = (cpx<T> *)p->bwork.p;
+    a.surface = (T *)d_surface;
+    a.part_val = (T *)p->bpart_val.p;
+    a.part_idx = (uint32_t *)p->bpart_idx.p;
+    if ((rc = timing_mark(p))) return rc;
+    for (size_t w0 = 0; w0 < total; w0 += 32768) {
+        const size_t nw = total - w0 < 32768 ? total - w0 : 32768;
+        a.wr0 = (unsigned)w0;
+        k_big_cols_fwd<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
+        k_big_rows<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
+        k_big_cols_inv<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
+    }
+    KCHK();
+    k_big_rowpeak<T><<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(
+        (const T *)p->bpart_val.p, (const uint32_t *)p->bpart_idx.p, total, d_ridx, (T *)d_rval);
+    KCHK();
+    if ((rc = timing_mark(p))) return rc;
+    return CAF_OK;
+}
+
 template <typename T>
 static int surface_dev_generic(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch,
                                void *d_surface, uint64_t *d_ridx, void *d_rval)
@@ -609,9 +690,11 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
     int rc;
     if (p->dtype == CAF_C128)
         rc = p->fused ? surface_dev_fused<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+             : p->big ? surface_dev_big<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
                       : surface_dev_generic<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     else
         rc = p->fused ? surface_dev_fused<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+             : p->big ? surface_dev_big<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
                       : surface_dev_generic<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     if (rc) return rc;
     // find_peak (mod.rs:31-42)

@@ -129,7 +129,8 @@ int caf_plan_create(caf_ctx *ctx, size_t n, const double *freqs_hz, size_t nfreq
                     uint32_t fs, int dtype, size_t row_begin, size_t row_end,
                     caf_plan **out);
 int caf_plan_destroy(caf_plan *plan);
-/* Name of the kernel path the plan selected: "fused4096" or "generic". */
+/* Name of the kernel path the plan selected: "fused4096" (n = 4096), "tiled65536"
+ * (n = 32768) or "generic" (any other power of two). */
 const char *caf_plan_path(const caf_plan *plan);
 size_t caf_plan_rows(const caf_plan *plan);
 /* Name of the dominant (row) kernel the plan launches, as rocprofv3 prints it without

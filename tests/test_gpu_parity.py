@@ -347,9 +347,9 @@ def test_streaming_double_buffer(eng, oracle, golden, manifest):
 
 
 # ------------------------------------------------------------ configs[3] shape --
-def test_L65536_c64_generic_path_rows(eng, oracle):
+def test_L65536_c64_tiled_path_rows(eng, oracle):
     """BASELINE configs[3] geometry (n = 32768 -> L = 65536, complex64) on a few Doppler
-    rows: the generic HBM-pass path against the f64 oracle, tolerance 1e-3 of max, and the
+    rows: the four-step tiled path against the f64 oracle, tolerance 1e-3 of max, and the
     synthetic pair's known (lag, Doppler) recovered."""
     import caf_cookoff_amd as caf
     from caf_cookoff_amd.synth import make_pair
@@ -357,13 +357,60 @@ def test_L65536_c64_generic_path_rows(eng, oracle):
     s0, s1, lag, fo = make_pair(n=n, seed=77, lag=173, foffset=12.0, dtype=np.complex64)
     fr = np.array([11.0, 11.5, 12.0, 12.5, 13.0])
     plan = eng.plan(n, fr, FS, dtype="c64")
-    assert plan.path == "generic"
+    assert plan.path == "tiled65536"
     plan.close()
     surf, ridx, rval, peak = eng.surface_arrays(s0, s1, fr, FS, dtype="c64")
     osurf, oidx, oval = oracle.np_caf_surface(s0.astype(np.complex128), s1.astype(np.complex128), fr, FS)
     assert surf.shape == (5, 65536)
     assert np.max(np.abs(surf - osurf)) <= TOL32 * osurf.max()
+    assert np.array_equal(ridx, oidx)
     assert (peak.freq, peak.idx) == (12.0, lag) == oracle.np_find_peak(fr, oidx, oval)
+    print(f"L=65536 c64: max|d|/max = {np.max(np.abs(surf - osurf)) / osurf.max():.3e}")
+
+
+def test_L65536_c128_tiled_path_and_negative_lag(eng, oracle):
+    """Same geometry in complex128 (tolerance 1e-6 of max), needle delayed w.r.t. the haystack
+    (negative lag -> index >= n), all-zero input, and a 2-surface batch through the plan."""
+    import torch
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.synth import make_pair
+    n = 32768
+    s0, s1, lag, fo = make_pair(n=n, seed=78, lag=90, foffset=-7.5)
+    fr = np.array([7.0, 7.5, 8.0])                                      # swapped roles: lag AND Doppler change sign
+    surf, ridx, rval, peak = eng.surface_arrays(s1, s0, fr, FS)
+    osurf, oidx, oval = oracle.np_caf_surface(s1, s0, fr, FS)
+    assert np.max(np.abs(surf - osurf)) <= TOL64 * osurf.max()
+    assert np.array_equal(ridx, oidx) and (peak.freq, int(peak.idx)) == (7.5, 65536 - lag)
+    z = np.zeros(n, dtype=np.complex128)
+    surf, ridx, rval, peak = eng.surface_arrays(z, z, fr, FS)
+    assert not surf.any() and (peak.freq, peak.idx, peak.row) == (0.0, 0, -1)
+    # batch of two surfaces, no surface output
+    plan = eng.plan(n, np.array([-7.5, 7.5]), FS)
+    nd = torch.from_numpy(np.stack([s0, s1])).cuda()
+    hs = torch.from_numpy(np.stack([s1, s0])).cuda()
+    r_i = torch.empty((2, 2), dtype=torch.int64, device="cuda")
+    r_v = torch.empty((2, 2), dtype=torch.float64, device="cuda")
+    pk = torch.empty((2, 4), dtype=torch.float64, device="cuda")
+    plan.surface_dev(nd.data_ptr(), hs.data_ptr(), 2, None, r_i.data_ptr(), r_v.data_ptr(), pk.data_ptr())
+    eng.synchronize()
+    torch.cuda.synchronize()
+    pkn = pk.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[:, 0]
+    assert (pkn[0]["freq"], int(pkn[0]["idx"])) == (-7.5, lag) and (pkn[1]["freq"], int(pkn[1]["idx"])) == (7.5, 65536 - lag)
+    plan.close()
+
+
+def test_generic_path_still_covers_other_big_sizes(eng, oracle):
+    """n = 16384 (L = 32768) has no fused kernel: generic HBM-pass path."""
+    from caf_cookoff_amd.synth import make_pair
+    n = 16384
+    s0, s1, lag, fo = make_pair(n=n, seed=79, lag=33, foffset=5.0)
+    fr = np.array([4.5, 5.0, 5.5])
+    plan = eng.plan(n, fr, FS)
+    assert plan.path == "generic"
+    plan.close()
+    surf, ridx, rval, peak = eng.surface_arrays(s0, s1, fr, FS)
+    osurf, oidx, oval = oracle.np_caf_surface(s0, s1, fr, FS)
+    assert np.max(np.abs(surf - osurf)) <= TOL64 * osurf.max() and (peak.freq, peak.idx) == (5.0, lag)
 
 
 # ------------------------------------------------- "next" rows of SURVEY.md 8(f) --

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE configs[3] shape (4096 x 65536 complex64) on ONE GPU's row shard through the
-generic HBM-pass path: 512 rows (= the 1/8 shard an 8-GPU job gives each rank)."""
+plan.s kernel path (tiled65536): 512 rows (= the 1/8 shard an 8-GPU job gives each rank)."""
 import sys
 import time
 from pathlib import Path
