@@ -103,6 +103,8 @@ def main():
                     "resident workgroup on 256 CUs x 2)")
     ap.add_argument("--dtype", choices=["c128", "c64"], default="c128")
     ap.add_argument("--nfreq", type=int, default=400)
+    ap.add_argument("--n", type=int, default=N_SAMP, help="samples per input (4096 = configs[1]/[2]; "
+                    "32768 with --nfreq 4096 --dtype c64 --batch 1 = configs[3])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -145,17 +147,18 @@ def main():
     cu, devname = eng.device_info()
 
     F = args.nfreq
+    n_samp = args.n
     freqs = caf.bench_shifts() if F == 400 else np.linspace(-100.0, 100.0, F, endpoint=False)
     lo, hi = caf.shard_range(F, rank, world)
     rows = hi - lo
     nsurf = args.batch * world  # surfaces per step (whole job)
     cdt = np.complex128 if args.dtype == "c128" else np.complex64
     rdt = torch.float64 if args.dtype == "c128" else torch.float32
-    nd_h, hs_h, lags, fos = make_batch(nsurf, N_SAMP, FS, seed0=1000, dtype=cdt)
+    nd_h, hs_h, lags, fos = make_batch(nsurf, n_samp, FS, seed0=1000, dtype=cdt)
     nd = torch.from_numpy(nd_h).to(dev)
     hs = torch.from_numpy(hs_h).to(dev)
-    plan = eng.plan(N_SAMP, freqs, FS, dtype=args.dtype, row_begin=lo, row_end=hi)
-    surf = torch.empty((nsurf, rows, 2 * N_SAMP), dtype=rdt, device=dev)
+    plan = eng.plan(n_samp, freqs, FS, dtype=args.dtype, row_begin=lo, row_end=hi)
+    surf = torch.empty((nsurf, rows, 2 * n_samp), dtype=rdt, device=dev)
     ridx = torch.empty((nsurf, rows), dtype=torch.int64, device=dev)
     rval = torch.empty((nsurf, rows), dtype=rdt, device=dev)
     peak = torch.empty((nsurf, 4), dtype=torch.float64, device=dev)  # caf_peak records (32 B)
@@ -224,17 +227,19 @@ def main():
     if rank == 0:
         value = nsurf * K / el
         kern_ms = kern_ms_total / max(1, launches)
-        abytes = algorithmic_bytes(nsurf, rows, N_SAMP, args.dtype)
+        abytes = algorithmic_bytes(nsurf, rows, n_samp, args.dtype)
         achieved = abytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic = profiled_traffic(plan.kernel_name, nsurf, args.dtype) if world == 1 else None
         res = {
-            "metric": "CAF surfaces/sec (400 freqs x 8192 samp, c128)" if (F == 400 and args.dtype == "c128")
-                      else f"CAF surfaces/sec ({F} freqs x 8192 samp, {args.dtype})",
+            "metric": "CAF surfaces/sec (400 freqs x 8192 samp, c128)"
+                      if (F == 400 and args.dtype == "c128" and n_samp == N_SAMP)
+                      else f"CAF surfaces/sec ({F} freqs x {2 * n_samp} samp, {args.dtype})",
             "value": value, "unit": "surfaces/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.dtype == "c128" else "f32", "data": "synthetic",
-            "config": {"workload": f"{F}x8192 {'complex128' if args.dtype == 'c128' else 'complex64'} filterbank CAF "
-                                   f"(BASELINE configs[{1 if args.dtype == 'c128' else 2}]), n=4096, fs=48000",
+            "config": {"workload": f"{F}x{2 * n_samp} {'complex128' if args.dtype == 'c128' else 'complex64'} "
+                                   f"filterbank CAF (BASELINE configs["
+                                   f"{3 if n_samp == 32768 else 1 if args.dtype == 'c128' else 2}]), n={n_samp}, fs=48000",
                        "surfaces_per_step": nsurf, "batch_per_gpu": args.batch,
                        "rows_per_gpu": rows, "parallelism": f"doppler-row-shard x{world}" if world > 1 else "single",
                        "kernel_path": plan.path, "device": devname, "cus": cu},
