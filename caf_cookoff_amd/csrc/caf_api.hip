@@ -613,8 +613,15 @@ static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay,
     a.part_val = (T *)p->bpart_val.p;
     a.part_idx = (uint32_t *)p->bpart_idx.p;
     if ((rc = timing_mark(p))) return rc;
-    for (size_t w0 = 0; w0 < total; w0 += 32768) {
-        const size_t nw = total - w0 < 32768 ? total - w0 : 32768;
+    // Rows are processed in chunks whose work rows (chunk x 64 Ki complex) fit the 256 MiB
+    // Infinity Cache: the two intermediate passes then hit on-die instead of streaming the
+    // whole work buffer through HBM three times.
+    static const size_t chunk_env = getenv("CAF_BIG_CHUNK") ? (size_t)atol(getenv("CAF_BIG_CHUNK")) : 0;
+    size_t chunk = chunk_env ? chunk_env : (128u << 20) / (B_L * sizeof(cpx<T>));
+    if (chunk < 1) chunk = 1;
+    if (chunk > 32768) chunk = 32768;
+    for (size_t w0 = 0; w0 < total; w0 += chunk) {
+        const size_t nw = total - w0 < chunk ? total - w0 : chunk;
         a.wr0 = (unsigned)w0;
         k_big_cols_fwd<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
         k_big_rows<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
