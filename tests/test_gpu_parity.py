@@ -462,3 +462,61 @@ def test_cli_demo(tmp_path):
     surf = np.fromfile(dump, dtype="<f8").reshape(400, 8192)
     fdx, tdx = np.unravel_index(np.argmax(surf), surf.shape)
     assert 4096 - tdx == 202  # main.go:35
+
+
+# ------------------------------------------------------------- C-ABI error paths --
+def test_capi_error_codes(eng):
+    """Status codes instead of panics (xcor_rustfft.rs:54-55 asserts, mod.rs unwraps):
+    every failure returns a code and leaves a message in caf_last_error_string()."""
+    import ctypes
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd import _lib
+    lib = eng.lib
+    fr = np.array([0.0, 1.0, 2.0])
+    dp = fr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    h = ctypes.c_void_p()
+    # bad shard range / dtype / length / fs
+    assert lib.caf_plan_create(eng._h, 4096, dp, 3, FS, _lib.CAF_C128, 2, 1, ctypes.byref(h)) == _lib.CAF_ERR_BAD_ARG
+    assert lib.caf_plan_create(eng._h, 4096, dp, 3, FS, _lib.CAF_C128, 0, 4, ctypes.byref(h)) == _lib.CAF_ERR_BAD_ARG
+    assert lib.caf_plan_create(eng._h, 4096, dp, 3, FS, 7, 0, 3, ctypes.byref(h)) == _lib.CAF_ERR_BAD_ARG
+    assert lib.caf_plan_create(eng._h, 4095, dp, 3, FS, _lib.CAF_C128, 0, 3, ctypes.byref(h)) == _lib.CAF_ERR_LENGTH
+    assert lib.caf_plan_create(eng._h, 0, dp, 3, FS, _lib.CAF_C128, 0, 3, ctypes.byref(h)) == _lib.CAF_ERR_LENGTH
+    assert lib.caf_plan_create(eng._h, 4096, dp, 3, 0, _lib.CAF_C128, 0, 3, ctypes.byref(h)) == _lib.CAF_ERR_BAD_ARG
+    assert b"fs == 0" in lib.caf_last_error_string()
+    assert h.value is None
+    # NULL arguments to the device entry point
+    plan = eng.plan(4096, fr, FS)
+    assert lib.caf_surface_dev(plan._h, None, None, 1, None, None, None, None) == _lib.CAF_ERR_BAD_ARG
+    # an empty shard is legal: no rows, peak = "no row"
+    empty = eng.plan(4096, fr, FS, row_begin=3, row_end=3)
+    assert empty.rows == 0
+    empty.close()
+    # streaming: bad slot / bad slot count
+    with pytest.raises(caf.CafError):
+        caf.Stream(plan, batch=1, nslots=1)
+    st = caf.Stream(plan, batch=1, nslots=2, want_surface=False)
+    assert lib.caf_stream_submit(st._h, 5) == _lib.CAF_ERR_BAD_ARG
+    assert st.surface_ptr(0) == 0
+    st.close()
+    plan.close()
+    # views: bad view id, n == 0
+    buf = np.zeros((1, 16))
+    assert lib.caf_surface_view(eng._h, _lib.CAF_C128, buf.ctypes.data, 1, 8, 9, buf.ctypes.data) == _lib.CAF_ERR_BAD_ARG
+    assert lib.caf_surface_view(eng._h, _lib.CAF_C128, buf.ctypes.data, 1, 0, 1, buf.ctypes.data) == _lib.CAF_ERR_LENGTH
+    # context for a device that does not exist
+    h2 = ctypes.c_void_p()
+    assert lib.caf_ctx_create(999, ctypes.byref(h2)) == _lib.CAF_ERR_NO_DEVICE
+
+
+def test_apply_freq_shift_c64_and_find_peak_direct(eng, golden):
+    """The c64 twin of mod.rs:46-65 (phase in f64, one rounding) and find_peak on caller rows."""
+    from caf_cookoff_amd import CafSurfaceRow
+    a = golden["vec4096_a"].astype(np.complex64)
+    out = eng.apply_freq_shift(a, 77.77, FS)
+    assert out.dtype == np.complex64 and out[0] == a[0]
+    ref = golden["vec4096_shift_77p77"]
+    assert np.max(np.abs(out.astype(np.complex128) - ref)) <= 2e-7 * np.max(np.abs(ref)) + 1e-9
+    rows = [CafSurfaceRow(1.0, None, 10, 3.0), CafSurfaceRow(2.0, None, 20, 5.0), CafSurfaceRow(3.0, None, 30, 5.0),
+            CafSurfaceRow(4.0, None, 40, 0.0)]
+    assert eng.find_peak(rows) == (2.0, 20)           # first strictly-greater row wins (mod.rs:36)
+    assert eng.find_peak(rows[3:]) == (0.0, 0)        # nothing above the initial 0.0 (mod.rs:32-35)
