@@ -13,6 +13,9 @@
 //   * register budget: 64 (v) + 64 (E stash) + twiddles.  Only W^(t), W^(2t), W^(3t), W^(4t),
 //     W^(8t), W^(12t) are held (24 VGPRs); the other nine W^(t(4a+b)) = W^(4at) W^(bt) cost one
 //     extra complex multiply each per use (+4 % VALU).
+//   * input loads are software-pipelined (PF bits below), LDS writes of each exchange are
+//     issued group by group from the last butterfly stage (dft16_sink), rows are handed out
+//     by a device-scope ticket counter.
 #pragma once
 #include "kernels_fused4096.hpp"
 
@@ -88,7 +91,6 @@ __device__ __forceinline__ void keep(cpx<T> &x)
 {
     asm volatile("" : "+v"(x.x), "+v"(x.y));
 }
-#define LDS_W(expr_addr, val) do { if constexpr (!(ABL & 1)) { expr_addr = (val); } else { C tmp__ = (val); keep(tmp__); v[k & 15] = tmp__; } } while (0)
 
 // PF (software pipelining of the input loads; each bit moves one group of loads earlier):
 //   1: even chain - haystack-spectrum loads issued right after the mixer
