@@ -161,6 +161,46 @@ __device__ __forceinline__ void dft16_sink(cpx<T> (&v)[16], F &&sink)
     }
 }
 
+// the six held twiddles W_4096^(t*k), k in {1,2,3,4,8,12}
+template <typename T>
+struct TwSet {
+    cpx<T> w1, w2, w3, w4, w8, w12;
+};
+
+// x * W_4096^(t*k) for a compile-time k (after unrolling): k = 4a + b -> W^(4a t) * W^(b t)
+template <typename T>
+__device__ __forceinline__ cpx<T> twA_k(cpx<T> x, int k, const TwSet<T> &w)
+{
+    const int a = k >> 2, b = k & 3;
+    if (a == 1) x = cmul(x, w.w4);
+    if (a == 2) x = cmul(x, w.w8);
+    if (a == 3) x = cmul(x, w.w12);
+    if (b == 1) x = cmul(x, w.w1);
+    if (b == 2) x = cmul(x, w.w2);
+    if (b == 3) x = cmul(x, w.w3);
+    return x;
+}
+
+template <typename T>
+__device__ __forceinline__ void apply_twA(cpx<T> (&v)[16], const TwSet<T> &w)
+{
+    v[1] = cmul(v[1], w.w1);
+    v[2] = cmul(v[2], w.w2);
+    v[3] = cmul(v[3], w.w3);
+    v[4] = cmul(v[4], w.w4);
+    v[5] = cmul(cmul(v[5], w.w4), w.w1);
+    v[6] = cmul(cmul(v[6], w.w4), w.w2);
+    v[7] = cmul(cmul(v[7], w.w4), w.w3);
+    v[8] = cmul(v[8], w.w8);
+    v[9] = cmul(cmul(v[9], w.w8), w.w1);
+    v[10] = cmul(cmul(v[10], w.w8), w.w2);
+    v[11] = cmul(cmul(v[11], w.w8), w.w3);
+    v[12] = cmul(v[12], w.w12);
+    v[13] = cmul(cmul(v[13], w.w12), w.w1);
+    v[14] = cmul(cmul(v[14], w.w12), w.w2);
+    v[15] = cmul(cmul(v[15], w.w12), w.w3);
+}
+
 // Orders this wave's LDS accesses without a workgroup barrier: LDS operations of
 // one wave execute in issue order, so a compiler-level fence is all that is needed
 // for the wave-local exchanges (the 256-element block a wave owns is read and
@@ -403,6 +443,8 @@ __device__ __forceinline__ cpx<float> bload(__amdgpu_buffer_rsrc_t rs, unsigned 
 }
 
 // ---- the row kernel ------------------------------------------------------------------------
+// (f32 at __launch_bounds__(512, 4) -- two workgroups = 4 waves per SIMD -- was measured:
+// 128 VGPRs cost 37 spills and 12 % of throughput.)
 template <typename T, bool DIAG = false>
 __global__ __launch_bounds__(F_THREADS) void k_fused_rows(const FusedArgs<T> A)
 {
@@ -416,10 +458,14 @@ __global__ __launch_bounds__(F_THREADS) void k_fused_rows(const FusedArgs<T> A)
     const FusedLane L;
     C *const Lc = lds + L.chain * F_CHAIN;
 
-    // ---- twiddles: W_4096^(t*k) in registers, W_256^(lo4*k) in LDS ---------------
-    C twA[16];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) twA[k] = A.tab.tw4096[L.t * k];
+    // ---- twiddles: six W_4096^(t*k) in registers (rest derived), W_256^(lo4*k) in LDS ---------
+    TwSet<T> tw;
+    tw.w1 = A.tab.tw4096[L.t * 1];
+    tw.w2 = A.tab.tw4096[L.t * 2];
+    tw.w3 = A.tab.tw4096[L.t * 3];
+    tw.w4 = A.tab.tw4096[L.t * 4];
+    tw.w8 = A.tab.tw4096[L.t * 8];
+    tw.w12 = A.tab.tw4096[L.t * 12];
     if (L.tid < 256) twb[L.tid] = A.tab.tw4096[16 * (L.tid & 15) * (L.tid >> 4)];
     const C *const twB = twb + L.lo4;  // twB[16*k]
     // last-stage twiddle base T^(t + 256*m2): lanes 0-31 end up owning m2 = 8+i -> extra *i
@@ -463,8 +509,7 @@ __global__ __launch_bounds__(F_THREADS) void k_fused_rows(const FusedArgs<T> A)
         CAF_STAMP(1);
         // ---- forward chain -------------------------------------------------------------
         dft16(v);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twA[k]);
+        apply_twA(v, tw);
         CAF_STAMP(2);
 #pragma unroll
         for (int k = 0; k < 16; ++k) Lc[L.pA + k * F_BLK] = v[k];
@@ -538,8 +583,7 @@ __global__ __launch_bounds__(F_THREADS) void k_fused_rows(const FusedArgs<T> A)
         // so the epilogue, the stores and the next mixer run barrier-free.
         __syncthreads();
         CAF_STAMP(14);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twA[k]);
+        apply_twA(v, tw);
         // ---- pass III: over k0 -> y[t + 256*m2], m2 = register ---------------------------
         dft16(v);
 

@@ -42,46 +42,6 @@ struct SeqLane {
     }
 };
 
-// the six held twiddles W_4096^(t*k), k in {1,2,3,4,8,12}
-template <typename T>
-struct TwSet {
-    cpx<T> w1, w2, w3, w4, w8, w12;
-};
-
-// x * W_4096^(t*k) for a compile-time k (after unrolling): k = 4a + b -> W^(4a t) * W^(b t)
-template <typename T>
-__device__ __forceinline__ cpx<T> twA_k(cpx<T> x, int k, const TwSet<T> &w)
-{
-    const int a = k >> 2, b = k & 3;
-    if (a == 1) x = cmul(x, w.w4);
-    if (a == 2) x = cmul(x, w.w8);
-    if (a == 3) x = cmul(x, w.w12);
-    if (b == 1) x = cmul(x, w.w1);
-    if (b == 2) x = cmul(x, w.w2);
-    if (b == 3) x = cmul(x, w.w3);
-    return x;
-}
-
-template <typename T>
-__device__ __forceinline__ void apply_twA(cpx<T> (&v)[16], const TwSet<T> &w)
-{
-    v[1] = cmul(v[1], w.w1);
-    v[2] = cmul(v[2], w.w2);
-    v[3] = cmul(v[3], w.w3);
-    v[4] = cmul(v[4], w.w4);
-    v[5] = cmul(cmul(v[5], w.w4), w.w1);
-    v[6] = cmul(cmul(v[6], w.w4), w.w2);
-    v[7] = cmul(cmul(v[7], w.w4), w.w3);
-    v[8] = cmul(v[8], w.w8);
-    v[9] = cmul(cmul(v[9], w.w8), w.w1);
-    v[10] = cmul(cmul(v[10], w.w8), w.w2);
-    v[11] = cmul(cmul(v[11], w.w8), w.w3);
-    v[12] = cmul(v[12], w.w12);
-    v[13] = cmul(cmul(v[13], w.w12), w.w1);
-    v[14] = cmul(cmul(v[14], w.w12), w.w2);
-    v[15] = cmul(cmul(v[15], w.w12), w.w3);
-}
-
 // One chain of one row: needle samples -> y[m2] = IDFT_4096(C_chain)[t + 256*m2].
 // 3 workgroup barriers; exchanges 2 and 3 are wave-local.
 // ABL (measurement builds only, wrong results): bit0 = no LDS traffic/barriers (values stay
