@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W            (N>1: launched by torchrun)
 
 A "step" is one pass of the hot path over one batch of synthetic input: `--batch`
-distinct (needle, haystack) pairs per GPU, each a 400 x 8192 complex128 filterbank
+(default 128) distinct (needle, haystack) pairs per GPU, each a 400 x 8192 complex128 filterbank
 CAF (BASELINE configs[1]: n = 4096 samples, 400 shifts -100..99.5 Hz, fs = 48 kHz),
 inputs resident in HBM, surfaces + per-row peaks + global peak left in HBM.
 
@@ -99,8 +99,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="surfaces per GPU per step (32 x 400 rows = 25 rows per "
-                    "resident workgroup on 256 CUs x 2)")
+    ap.add_argument("--batch", type=int, default=128, help="surfaces per GPU per step (128 x 400 rows = 100 rows "
+                    "per resident workgroup on 256 CUs x 2; throughput saturates from ~128: profiles/r01_v4)")
     ap.add_argument("--dtype", choices=["c128", "c64"], default="c128")
     ap.add_argument("--nfreq", type=int, default=400)
     ap.add_argument("--n", type=int, default=N_SAMP, help="samples per input (4096 = configs[1]/[2]; "
