@@ -132,10 +132,10 @@ __device__ __forceinline__ void dft16(cpx<T> (&v)[16])
 }
 
 // dft16 whose outputs are handed to `sink(k, X[k])` as soon as each radix-4 group of the
-// second stage retires, with a scheduling fence per group: the caller's twiddle multiply +
-// ds_write of four outputs then sits between butterfly groups instead of all sixteen
-// ds_write_b128 piling up behind the math (four waves doing that at once queue 64 stores on
-// the CU's LDS store path and stall in-order issue; SQ_WAIT_INST_LDS in profiles/r01_v2).
+// second stage retires: the caller's twiddle multiply + ds_write of four outputs can then sit
+// between butterfly groups instead of all sixteen ds_write_b128 piling up behind the math
+// (SQ_WAIT_INST_LDS in profiles/).  Measured effect: within noise, with or without a
+// scheduling fence per group.
 template <typename T, typename F>
 __device__ __forceinline__ void dft16_sink(cpx<T> (&v)[16], F &&sink)
 {
@@ -157,7 +157,6 @@ __device__ __forceinline__ void dft16_sink(cpx<T> (&v)[16], F &&sink)
         dft4(v[4 * r0], v[4 * r0 + 1], v[4 * r0 + 2], v[4 * r0 + 3]);  // X[r0 + 4*r1] at v[4*r0 + r1]
 #pragma unroll
         for (int r1 = 0; r1 < 4; ++r1) sink(r0 + 4 * r1, v[4 * r0 + r1]);
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
