@@ -541,7 +541,7 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
         static const int wg_env = getenv("CAF_WG_PER_CU") ? atoi(getenv("CAF_WG_PER_CU")) : 0;
         if (wg_env > 0) per_cu = (size_t)wg_env;
         const size_t cap = (size_t)c->cu_count * per_cu;
-        k_seq_rows<T, 0, 8, 15><<<(unsigned)(total < cap ? total : cap), S_THREADS, 0, c->stream>>>(a);
+        k_seq_rows<T, 0, 8, 15><<<(unsigned)(total < cap ? total : cap), S_THREADS, 0, c->stream>>>(a, a.phasor);
     } else if (p->variant == 0 && !p->dbg) {
         size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
         if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();  // VGPR-limited
@@ -551,14 +551,14 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
         const unsigned grid = (unsigned)(total < cap ? total : cap);
         static const int store_mode = getenv("CAF_STORE_MODE") ? atoi(getenv("CAF_STORE_MODE")) : 0;
         switch (store_mode) {  // 1-3: measurement variants only
-        case 1: k_seq_rows<T, 1><<<grid, S_THREADS, 0, c->stream>>>(a); break;
-        case 2: k_seq_rows<T, 2><<<grid, S_THREADS, 0, c->stream>>>(a); break;
-        case 3: k_seq_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a); break;
-        case 11: k_seq_rows<T, 0, 1, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // no LDS
-        case 12: k_seq_rows<T, 0, 2, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // no global loads
-        case 13: k_seq_rows<T, 3, 3, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;  // VALU only
-        case 20: k_seq_rows<T, 0, 0, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;   // no software pipelining
-        default: k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a); break;
+        case 1: k_seq_rows<T, 1><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
+        case 2: k_seq_rows<T, 2><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
+        case 3: k_seq_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
+        case 11: k_seq_rows<T, 0, 1, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS
+        case 12: k_seq_rows<T, 0, 2, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no global loads
+        case 13: k_seq_rows<T, 3, 3, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // VALU only
+        case 20: k_seq_rows<T, 0, 0, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;   // no software pipelining
+        default: k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         }
     } else {
         const size_t per_cu = fused_lds_bytes<T>() * 2 <= 160 * 1024 ? 2 : 1;

@@ -61,14 +61,6 @@ __global__ void k_r8_phasors(const double *__restrict__ ph, int nrows, cpx<T> *_
     tab[(size_t)row * 64 + e] = {(T)(co * c2 - s * s2), (T)(co * s2 + s * c2)};
 }
 
-// th512[t] = e^{2*pi*i*t/8192}, t < 512
-template <typename T>
-__global__ void k_r8_tables(cpx<T> *__restrict__ th512)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 512) th512[i] = cispi_f64<T>(2.0 * (double)i / 8192.0);
-}
-
 // ---- radix-8 butterfly, positive exponent, natural order in and out --------------------
 template <typename T>
 __device__ __forceinline__ void dft8(cpx<T> (&v)[8])

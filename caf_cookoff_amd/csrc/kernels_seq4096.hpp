@@ -77,8 +77,8 @@ constexpr int S_NSTAMP = 24;
 
 template <typename T, int CH, int ABL = 0, int PF = 0>
 __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t rs_sig,
-                                          const __amdgpu_buffer_rsrc_t rs_spec, const cpx<T> *ph,
-                                          const cpx<T> cfac, const TwSet<T> &tw, const cpx<T> *twB,
+                                          const __amdgpu_buffer_rsrc_t rs_spec, const cpx<T> pb,
+                                          const cpx<T> *__restrict__ ps, const TwSet<T> &tw, const cpx<T> *twB,
                                           cpx<T> *Lc, const SeqLane &L, unsigned long long (&st)[S_NSTAMP])
 {
     SEQ_STAMP(0);
@@ -95,9 +95,6 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
             if constexpr (ABL & 2) { a[q] = C{T(q + 1), T(L.t)}; keep(a[q]); }
         }
         if constexpr (!(ABL & 2) && !A_PRELOADED) load_samples(a, rs_sig, L);
-        C pb = cmul(ph[L.lo4], ph[16 + L.hi4]);
-        if (CH) pb = cmul(pb, cfac);
-        const C *ps = ph + 32 + CH * 16;
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = conj(cmul(cmul(a[q], pb), ps[q]));
     }
@@ -199,8 +196,12 @@ __device__ constexpr double W32S16[16] = {0.0, 0.1950903220161282678482848684770
 template <typename T>
 constexpr int seq_waves_per_simd() { return sizeof(T) == 8 ? 2 : 2; }
 
+// `phasor` is passed as its own __restrict__ parameter (not inside FusedArgs) so that the
+// wave-uniform step entries become scalar loads: they cost no vector-memory issue slot and,
+// unlike vector loads, are not ordered behind the epilogue's stores by the in-order vmcnt.
 template <typename T, int STORE = 0, int ABL = 0, int PF = 15>
-__global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows(const FusedArgs<T> A)
+__global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows(const FusedArgs<T> A,
+                                                                             const cpx<T> *__restrict__ phasor)
 {
     using C = cpx<T>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[seq_lds_bytes<T>()];
@@ -241,23 +242,30 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
     // within one row time.  Tickets are in surface-major order, so at any moment the whole chip
     // works on 1-2 surfaces and their inputs stay L2-resident, as with static striding.
     volatile int *const next_row = reinterpret_cast<volatile int *>(scratch + 48);
+    // phasor base w^t of the first row (later rows: fetched in the previous row's epilogue)
+    C pb;
+    {
+        const int g0 = (int)blockIdx.x < A.total ? (int)blockIdx.x : A.total - 1;
+        const C *ph0 = phasor + (size_t)(g0 % A.rows) * 64;
+        pb = cmul(ph0[L.lo4], ph0[16 + L.hi4]);
+    }
     for (int g = blockIdx.x; g < A.total;) {
         if (L.tid == 0)
             *next_row = A.work ? (int)gridDim.x + (int)atomicAdd(A.work, 1u) : g + (int)gridDim.x;
         const int b = g / A.rows, r = g - b * A.rows;
-        const C *ph = A.phasor + (size_t)r * 64;
+        const C *__restrict__ ph = phasor + (size_t)r * 64;
         const __amdgpu_buffer_rsrc_t rs_sig =
             __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)b * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.spec + (size_t)b * (2 * 16 * 256)), 0, 2 * 16 * 256 * (int)sizeof(C), 0x00020000);
         C e[16], o[16];
-        seq_chain<T, 0, ABL, PF>(e, a, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L, st);
+        seq_chain<T, 0, ABL, PF>(e, a, rs_sig, rs_spec, pb, ph + 32, tw, twB, Lc, L, st);
         // the ticket was stored before the chain's barriers: visible to every wave by now
         const int gn = __builtin_amdgcn_readfirstlane(*next_row);
         const int gc = gn < A.total ? gn : A.total - 1;  // clamped: a[] is always redefined
         const __amdgpu_buffer_rsrc_t rs_sig_next = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
-        seq_chain<T, 1, ABL, PF>(o, a, rs_sig, rs_spec, ph, cfac, tw, twB, Lc, L, st);
+        seq_chain<T, 1, ABL, PF>(o, a, rs_sig, rs_spec, cmul(pb, cfac), ph + 48, tw, twB, Lc, L, st);
 
         // ---- last radix-2 stage (in registers) + |.|^2 + argmax + 16-B write-through stores --
         T bv_lo = T(0), bv_hi = T(0);
@@ -265,28 +273,35 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
         T *const out = A.surface ? A.surface + (size_t)g * F_L : nullptr;
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? F_L * (int)sizeof(T) : 0, 0x00020000);
+        // All magnitudes first; each retired (e[i], o[i]) pair frees the registers that receive the
+        // next row's needle sample.  Every load of the next row is issued BEFORE the first store:
+        // vmcnt retires in order, so a load issued after the 16 write-through stores could not be
+        // consumed until those stores had reached memory.
+        T mlo[16], mhi[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {  // m = t + 256*i
+            const C w32 = {(T)W32C16[i], (T)W32S16[i]};
+            const C z = cmul(cmul(o[i], th), w32);  // T^m * O[m]
+            mlo[i] = norm_sqr(e[i] + z);            // mod.rs:147
+            mhi[i] = norm_sqr(e[i] - z);
+            if (mlo[i] > bv_lo) { bv_lo = mlo[i]; bi_lo = i; }
+            if (mhi[i] > bv_hi) { bv_hi = mhi[i]; bi_hi = i; }
+            if constexpr (PF & 8)
+                a[i] = bload(rs_sig_next, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * i * sizeof(C)), (C *)nullptr);
+        }
+        {   // phasor base of the next row
+            const C *phn = phasor + (size_t)(gc % A.rows) * 64;
+            pb = cmul(phn[L.lo4], phn[16 + L.hi4]);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            T mlo[2], mhi[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = 2 * j + u;  // m = t + 256*i
-                const C w32 = {(T)W32C16[i], (T)W32S16[i]};
-                const C z = cmul(cmul(o[i], th), w32);  // T^m * O[m]
-                mlo[u] = norm_sqr(e[i] + z);            // mod.rs:147
-                mhi[u] = norm_sqr(e[i] - z);
-                if (mlo[u] > bv_lo) { bv_lo = mlo[u]; bi_lo = i; }
-                if (mhi[u] > bv_hi) { bv_hi = mhi[u]; bi_hi = i; }
-                if constexpr (PF & 8)  // e[i], o[i] are dead: their registers take the next row's sample
-                    a[i] = bload(rs_sig_next, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * i * sizeof(C)), (C *)nullptr);
-            }
-            const T slo = dpp_xor1<T>(odd ? mlo[0] : mlo[1]);
-            const T shi = dpp_xor1<T>(odd ? mhi[0] : mhi[1]);
+            const T slo = dpp_xor1<T>(odd ? mlo[2 * j] : mlo[2 * j + 1]);
+            const T shi = dpp_xor1<T>(odd ? mhi[2 * j] : mhi[2 * j + 1]);
             const int m = mpair + 256 * (2 * j + (odd ? 1 : 0));
             if constexpr (STORE != 3) {
                 constexpr int AUX = STORE == 0 ? CAF_AUX_SC1 : STORE == 2 ? 2 : 0;
-                store_pair_aux<AUX>(rs, (unsigned)(m * sizeof(T)), odd ? slo : mlo[0], odd ? mlo[1] : slo);
-                store_pair_aux<AUX>(rs, (unsigned)((m + F_N) * sizeof(T)), odd ? shi : mhi[0], odd ? mhi[1] : shi);
+                store_pair_aux<AUX>(rs, (unsigned)(m * sizeof(T)), odd ? slo : mlo[2 * j], odd ? mlo[2 * j + 1] : slo);
+                store_pair_aux<AUX>(rs, (unsigned)((m + F_N) * sizeof(T)), odd ? shi : mhi[2 * j], odd ? mhi[2 * j + 1] : shi);
             } else {
                 asm volatile("" ::"v"(slo), "v"(shi));
             }
