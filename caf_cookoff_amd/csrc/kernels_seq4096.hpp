@@ -43,7 +43,7 @@ struct SeqLane {
 };
 
 // One chain of one row: needle samples -> y[m2] = IDFT_4096(C_chain)[t + 256*m2].
-// 3 workgroup barriers; exchanges 2 and 3 are wave-local.
+// 2 workgroup barriers; exchanges 2 and 3 are wave-local.
 // ABL (measurement builds only, wrong results): bit0 = no LDS traffic/barriers (values stay
 // in registers), bit1 = no global loads (operands synthesised), bit2 = no butterfly math.
 template <typename T>
@@ -163,8 +163,10 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
         SEQ_STAMP(8);  // barrier ex4
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = Lc[L.pA + k * F_BLK];
-        __syncthreads();  // all LDS reads of this chain done: the next chain may write
-        SEQ_STAMP(9);  // ex4 read + barrier
+        // No barrier here: the next exchange-1 write (pattern A) of this thread overwrites exactly
+        // the sixteen addresses it has just read, and nobody else touches them before the barrier
+        // that follows that write.
+        SEQ_STAMP(9);  // ex4 read
     }
     // the odd chain reads the same needle samples: fetch them under the last butterfly
     if constexpr (CH == 0 && (PF & 2) && !(ABL & 2)) load_samples(a, rs_sig, L);
