@@ -12,7 +12,8 @@ N > 1 (weak scaling): the step covers N*batch surfaces; ra
 computes the contiguous Doppler-row shard [r*F/N, (r+1)*F/N) of EVERY surface, then
 one RCCL all-reduce(max) over the N*batch peak values and one all-reduce(min) over
 (global_row<<32|idx) keys of the ranks that hold the max give every surface's global
-(tau, f) with the reference's first-row-wins tie-break.  Per-GPU work is constant.
+(tau, f) with the reference's first-row-wins tie-break (--peak-reduce allgather does the
+same with a single all_gather).  Per-GPU work is constant.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 (dominant kernel, HBM bound, algorithmic bytes / HIP-event kernel time) and
@@ -109,6 +110,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--peak-reduce", choices=["allreduce", "allgather"], default="allreduce",
+                    help="N>1: RCCL all-reduce(max) + all-reduce(min key) (BASELINE north_star), or one all_gather")
     args = ap.parse_args()
 
     import torch
@@ -174,8 +177,8 @@ def main():
         if rehearse:
             pk_c = peak.cpu()
             pk_ci = pk_c.view(torch.int64)
-            return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2])
-        return reduce_global_peak(peak[:, 0], peak_i[:, 3], peak_i[:, 2])
+            return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2], method=args.peak_reduce)
+        return reduce_global_peak(peak[:, 0], peak_i[:, 3], peak_i[:, 2], method=args.peak_reduce)
 
     def sync_all():
         torch.cuda.synchronize()
