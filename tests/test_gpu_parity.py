@@ -520,3 +520,34 @@ def test_apply_freq_shift_c64_and_find_peak_direct(eng, golden):
             CafSurfaceRow(4.0, None, 40, 0.0)]
     assert eng.find_peak(rows) == (2.0, 20)           # first strictly-greater row wins (mod.rs:36)
     assert eng.find_peak(rows[3:]) == (0.0, 0)        # nothing above the initial 0.0 (mod.rs:32-35)
+
+
+# ------------------------------------------------ full-size domain properties --
+def test_full_size_properties(eng, oracle):
+    """Size-independent properties on the full 400 x 8192 shape (no oracle involved):
+    |alpha|^2 scaling of the surface, delay covariance of the lag axis, and invariance of
+    the row peaks under a common phase rotation of both inputs."""
+    nd, hs = _pair(oracle, 7)
+    fr = oracle.bench_shifts()
+    surf, ridx, rval, peak = eng.surface_arrays(nd, hs, fr, FS)
+    smax = surf.max()
+    # scaling: needle * alpha  ->  surface * |alpha|^2, same argmax everywhere
+    alpha = 0.5 - 1.25j
+    s2, i2, v2, p2 = eng.surface_arrays(alpha * nd, hs, fr, FS)
+    assert np.max(np.abs(s2 - abs(alpha) ** 2 * surf)) <= 1e-12 * abs(alpha) ** 2 * smax
+    assert np.array_equal(i2, ridx) and (p2.freq, p2.idx) == (peak.freq, peak.idx)
+    # common phase rotation of both inputs leaves |.|^2 unchanged
+    rot = np.exp(0.7j)
+    s3, i3, v3, p3 = eng.surface_arrays(rot * nd, rot * hs, fr, FS)
+    assert np.max(np.abs(s3 - surf)) <= 1e-12 * smax and np.array_equal(i3, ridx)
+    # delay covariance: a haystack with exact zeros at both ends, delayed by d samples (nothing
+    # wraps or is truncated), moves every lag of the 2n-periodic lag axis by d
+    d = 37
+    hs_a = np.concatenate([np.zeros(50, dtype=nd.dtype), nd[:4096 - 100] * np.exp(2j * np.pi * 20.0 * np.arange(3996) / FS),
+                           np.zeros(50, dtype=nd.dtype)])
+    hs_b = np.concatenate([np.zeros(d, dtype=nd.dtype), hs_a[:-d]])
+    fr2 = fr[::16]
+    s_a, i_a, v_a, p_a = eng.surface_arrays(nd, hs_a, fr2, FS)
+    s_b, i_b, v_b, p_b = eng.surface_arrays(nd, hs_b, fr2, FS)
+    assert np.max(np.abs(np.roll(s_a, d, axis=1) - s_b)) <= 1e-12 * s_a.max()
+    assert (p_b.freq, p_b.idx) == (p_a.freq, p_a.idx + d) and p_a.idx == 50
