@@ -175,6 +175,63 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
     SEQ_STAMP(10);  // twA + DFT#6
 }
 
+// ---- haystack spectrum, one 256-thread workgroup per (surface, chain) ------------------------
+// Hs = FFT_8192(haystack ++ 0)/8192 = conj(IDFT(conj h))/L in the register layout the row
+// kernels multiply in: spec[b][chain][k2][t].  Also zeroes the row-ticket counter of the row
+// kernel that follows on the stream.
+template <typename T>
+__global__ __launch_bounds__(S_THREADS) void k_seq_prepare(const FusedArgs<T> A, const cpx<T> *__restrict__ phasor)
+{
+    using C = cpx<T>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[seq_lds_bytes<T>()];
+    C *const Lc = reinterpret_cast<C *>(smem);
+    C *const twb = Lc + F_CHAIN;
+    const SeqLane L;
+    TwSet<T> tw;
+    tw.w1 = A.tab.tw4096[L.t * 1];
+    tw.w2 = A.tab.tw4096[L.t * 2];
+    tw.w3 = A.tab.tw4096[L.t * 3];
+    tw.w4 = A.tab.tw4096[L.t * 4];
+    tw.w8 = A.tab.tw4096[L.t * 8];
+    tw.w12 = A.tab.tw4096[L.t * 12];
+    twb[L.tid] = A.tab.tw4096[16 * (L.tid & 15) * (L.tid >> 4)];
+    const C *const twB = twb + L.lo4;
+    if (blockIdx.x == 0 && L.tid == 0 && A.work) *A.work = 0u;
+    const C *__restrict__ ph = phasor + (size_t)A.rows * 64;  // the f = 0 row
+    const T inv = T(1.0 / 8192.0);
+    __syncthreads();
+    for (int w = blockIdx.x; w < 2 * A.total; w += gridDim.x) {
+        const int b = w >> 1, chain = w & 1;
+        const C *sig = A.sig + (size_t)b * F_N;
+        C pb = cmul(ph[L.lo4], ph[16 + L.hi4]);
+        if (chain) pb = cmulc(pb, A.tab.th[L.t]);
+        const C *ps = ph + 32 + 16 * chain;
+        C v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = conj(cmul(cmul(sig[L.t + 256 * q], pb), ps[q]));
+        dft16(v);
+        apply_twA(v, tw);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Lc[L.pA + k * F_BLK] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
+        dft16(v);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twB[16 * k]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Lc[L.pB + 17 * k] = v[k];
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pC + k];
+        dft16(v);
+        C *spec = A.spec + (size_t)b * (2 * 16 * 256) + chain * (16 * 256);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) spec[k * 256 + L.t] = {v[k].x * inv, -v[k].y * inv};
+        __syncthreads();  // the next iteration's pattern-A writes vs this one's pattern-B/C reads
+    }
+}
+
 // W_32^m2, m2 < 16
 __device__ constexpr double W32C16[16] = {1.0, 0.98078528040323044912618223613424, 0.92387953251128675612818318939679,
                                           0.83146961230254523707878837761791, 0.70710678118654752440084436210485,

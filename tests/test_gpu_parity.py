@@ -302,6 +302,42 @@ def test_plan_batch_and_shards(eng, oracle, golden, manifest):
         eng.set_stream(None)
 
 
+def test_batch_of_all_kat_pairs_ticket_path(eng, oracle, golden):
+    """Ten surfaces in one launch (4000 rows: the dynamic row-ticket assignment; one surface
+    alone takes the static stride) must equal the single-surface results bit for bit, on a
+    second launch as well (the ticket counter is re-armed by the prepare kernel)."""
+    import torch
+    fr = oracle.bench_shifts()
+    pairs = [_pair(oracle, k) for k in range(10)]
+    nd = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    hs = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    plan = eng.plan(4096, fr, FS)
+    surf = torch.empty((10, 400, 8192), dtype=torch.float64, device="cuda")
+    ridx = torch.empty((10, 400), dtype=torch.int64, device="cuda")
+    rval = torch.empty((10, 400), dtype=torch.float64, device="cuda")
+    peak = torch.empty((10, 4), dtype=torch.float64, device="cuda")
+    one_s = torch.empty((1, 400, 8192), dtype=torch.float64, device="cuda")
+    one_i = torch.empty((1, 400), dtype=torch.int64, device="cuda")
+    one_v = torch.empty((1, 400), dtype=torch.float64, device="cuda")
+    one_p = torch.empty((1, 4), dtype=torch.float64, device="cuda")
+    for rep in range(2):
+        surf.fill_(-1.0)
+        eng.synchronize(); torch.cuda.synchronize()
+        plan.surface_dev(nd.data_ptr(), hs.data_ptr(), 10, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(),
+                         peak.data_ptr())
+        eng.synchronize()
+        for b in range(10):
+            plan.surface_dev(nd[b].data_ptr(), hs[b].data_ptr(), 1, one_s.data_ptr(), one_i.data_ptr(),
+                             one_v.data_ptr(), one_p.data_ptr())
+            eng.synchronize()
+            assert torch.equal(surf[b], one_s[0]) and torch.equal(ridx[b], one_i[0]) and torch.equal(rval[b], one_v[0])
+            assert torch.equal(peak[b], one_p[0])
+    # bench-config goldens for the two pairs that have them
+    for b in (0, 4):
+        assert np.array_equal(ridx[b].cpu().numpy().astype(np.uint64), golden[f"bench{b}_row_idx"])
+    plan.close()
+
+
 # ------------------------------------------------------------------ streaming --
 def test_streaming_double_buffer(eng, oracle, golden, manifest):
     """BASELINE configs[4] mechanics: pinned double-buffered H2D + one hipGraph per slot;
