@@ -560,6 +560,7 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
         case 1: k_seq_rows<T, 1><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         case 2: k_seq_rows<T, 2><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         case 3: k_seq_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
+        case 4: k_seq_rows<T, 4><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         case 11: k_seq_rows<T, 0, 1, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS
         case 12: k_seq_rows<T, 0, 2, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no global loads
         case 13: k_seq_rows<T, 3, 3, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // VALU only

@@ -41,6 +41,11 @@ __device__ __forceinline__ cpx<T> muli(cpx<T> a) { return {-a.y, a.x}; }
 template <typename T>
 __device__ __forceinline__ T norm_sqr(cpx<T> a) { return a.x * a.x + a.y * a.y; }  // mod.rs:147
 
+__device__ __forceinline__ double vfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double vmax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+
 // e^{j*ang}, angle in f64 radians, rounded once to T (never
 // run the phasor in f32).
 template <typename T>

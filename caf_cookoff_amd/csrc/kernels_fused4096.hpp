@@ -180,6 +180,30 @@ __device__ __forceinline__ cpx<T> twA_k(cpx<T> x, int k, const TwSet<T> &w)
     return x;
 }
 
+// Same twiddles with a lane-wide common factor c folded in: q[b] = W^(b t) * c (q[0] = c), so
+// x * W^(t k) * c costs one multiply by W^(4a t) (a != 0) and one by q[b] -- the factor is free
+// for 12 of the 16 elements and costs 3 + 4 multiplies per use instead of 16.
+template <typename T>
+struct TwFold {
+    cpx<T> q[4];
+    __device__ __forceinline__ TwFold(const TwSet<T> &w, cpx<T> c)
+    {
+        q[0] = c;
+        q[1] = cmul(w.w1, c);
+        q[2] = cmul(w.w2, c);
+        q[3] = cmul(w.w3, c);
+    }
+};
+template <typename T>
+__device__ __forceinline__ cpx<T> twA_k(cpx<T> x, int k, const TwSet<T> &w, const TwFold<T> &f)
+{
+    const int a = k >> 2, b = k & 3;
+    if (a == 1) x = cmul(x, w.w4);
+    if (a == 2) x = cmul(x, w.w8);
+    if (a == 3) x = cmul(x, w.w12);
+    return cmul(x, f.q[b]);
+}
+
 template <typename T>
 __device__ __forceinline__ void apply_twA(cpx<T> (&v)[16], const TwSet<T> &w)
 {
@@ -422,6 +446,72 @@ __device__ __forceinline__ void store_pair_aux(__amdgpu_buffer_rsrc_t rs, unsign
     caf_v2u d = {__float_as_uint(x0), __float_as_uint(x1)};
     __builtin_amdgcn_raw_buffer_store_b64(d, rs, byte_off, 0, AUX);
 }
+template <int AUX>
+__device__ __forceinline__ void store_one_aux(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, double x)
+{
+    const long long a = __double_as_longlong(x);
+    caf_v2u d = {(unsigned)a, (unsigned)(a >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff, soff, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void store_one_aux(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float x)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, voff, soff, AUX);
+}
+// Lane pairing for the 16-B (f64) / 8-B (f32) surface stores.  Every lane holds x0 = element of
+// register row 2j and x1 = element of row 2j+1 at lag position t; lanes (2p, 2p+1) hold
+// consecutive lags.  The even lane stores row 2j's pair (own x0, partner's x0), the odd lane row
+// 2j+1's pair (partner's x1, own x1).  v_cndmask_b32_dpp does the neighbour fetch and the
+// select in ONE instruction per dword: D = vcc ? src1 : dpp(src0).
+// (s_nop 1: a DPP operand may have been written by the preceding VALU instruction; the
+// compiler's hazard recogniser does not look inside inline asm.)
+#define CAF_DPP_X1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+__device__ __forceinline__ void pair_xor1(double x0, double x1, unsigned long long even_mask,
+                                          unsigned long long odd_mask, caf_v4u &d)
+{
+    const unsigned x0l = (unsigned)__double_as_longlong(x0), x0h = (unsigned)(__double_as_longlong(x0) >> 32);
+    const unsigned x1l = (unsigned)__double_as_longlong(x1), x1h = (unsigned)(__double_as_longlong(x1) >> 32);
+    unsigned a, b, c, e;
+    asm("s_nop 1\n\t"
+        "s_mov_b64 vcc, %[ev]\n\t"
+        "v_cndmask_b32_dpp %[a], %[x1l], %[x0l], vcc " CAF_DPP_X1 "\n\t"
+        "v_cndmask_b32_dpp %[b], %[x1h], %[x0h], vcc " CAF_DPP_X1 "\n\t"
+        "s_mov_b64 vcc, %[od]\n\t"
+        "v_cndmask_b32_dpp %[c], %[x0l], %[x1l], vcc " CAF_DPP_X1 "\n\t"
+        "v_cndmask_b32_dpp %[e], %[x0h], %[x1h], vcc " CAF_DPP_X1
+        : [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [e] "=&v"(e)
+        : [x0l] "v"(x0l), [x0h] "v"(x0h), [x1l] "v"(x1l), [x1h] "v"(x1h), [ev] "s"(even_mask), [od] "s"(odd_mask)
+        : "vcc");
+    d = caf_v4u{a, b, c, e};
+}
+__device__ __forceinline__ void pair_xor1(float x0, float x1, unsigned long long even_mask,
+                                          unsigned long long odd_mask, caf_v2u &d)
+{
+    unsigned a, c;
+    asm("s_nop 1\n\t"
+        "s_mov_b64 vcc, %[ev]\n\t"
+        "v_cndmask_b32_dpp %[a], %[x1], %[x0], vcc " CAF_DPP_X1 "\n\t"
+        "s_mov_b64 vcc, %[od]\n\t"
+        "v_cndmask_b32_dpp %[c], %[x0], %[x1], vcc " CAF_DPP_X1
+        : [a] "=&v"(a), [c] "=&v"(c)
+        : [x0] "v"(__float_as_uint(x0)), [x1] "v"(__float_as_uint(x1)), [ev] "s"(even_mask), [od] "s"(odd_mask)
+        : "vcc");
+    d = caf_v2u{a, c};
+}
+template <int AUX>
+__device__ __forceinline__ void store_vec_aux(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, caf_v4u d)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, byte_off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void store_vec_aux(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, caf_v2u d)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(d, rs, byte_off, 0, AUX);
+}
+template <typename T> struct pair_vec;
+template <> struct pair_vec<double> { using type = caf_v4u; };
+template <> struct pair_vec<float> { using type = caf_v2u; };
+
 template <typename T>
 __device__ __forceinline__ void store_pair_wt(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, T x0, T x1)
 {

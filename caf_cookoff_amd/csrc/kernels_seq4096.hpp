@@ -77,7 +77,7 @@ constexpr int S_NSTAMP = 24;
 
 template <typename T, int CH, int ABL = 0, int PF = 0>
 __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t rs_sig,
-                                          const __amdgpu_buffer_rsrc_t rs_spec, const cpx<T> pb,
+                                          const __amdgpu_buffer_rsrc_t rs_spec, const cpx<T> pb, const cpx<T> post,
                                           const cpx<T> *__restrict__ ps, const TwSet<T> &tw, const cpx<T> *twB,
                                           cpx<T> *Lc, const SeqLane &L, unsigned long long (&st)[S_NSTAMP])
 {
@@ -96,8 +96,11 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
         }
         if constexpr (!(ABL & 2) && !A_PRELOADED) load_samples(a, rs_sig, L);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = conj(cmul(cmul(a[q], pb), ps[q]));
+        // conj(a * w^t * step[q]) = conj(a * step[q]) * conj(w^t): the lane factor conj(w^t)
+        // commutes with the first butterfly and is folded into its output twiddles (TwFold)
+        for (int q = 0; q < 16; ++q) v[q] = conj(cmul(a[q], ps[q]));
     }
+    const TwFold<T> fmix(tw, conj(pb));
     if constexpr (H_EARLY) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
@@ -107,12 +110,12 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
     if constexpr (ABL & 1) {
         dft16(v);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { v[k] = twA_k(v[k], k, tw); keep(v[k]); }
+        for (int k = 0; k < 16; ++k) { v[k] = twA_k(v[k], k, tw, fmix); keep(v[k]); }
         dft16(v);
 #pragma unroll
         for (int k = 1; k < 16; ++k) { v[k] = cmul(v[k], tw.w3); keep(v[k]); }
     } else {
-        dft16_sink(v, [&](int k, C x) { Lc[L.pA + k * F_BLK] = twA_k(x, k, tw); });
+        dft16_sink(v, [&](int k, C x) { Lc[L.pA + k * F_BLK] = twA_k(x, k, tw, fmix); });
         SEQ_STAMP(2);  // DFT#1 + twA + ex1 writes retired
         __syncthreads();
         SEQ_STAMP(3);  // barrier ex1
@@ -170,7 +173,13 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
     }
     // the odd chain reads the same needle samples: fetch them under the last butterfly
     if constexpr (CH == 0 && (PF & 2) && !(ABL & 2)) load_samples(a, rs_sig, L);
-    apply_twA(v, tw);
+    if constexpr (CH == 1) {  // odd chain: T^t of the last radix-2 stage folded into the twiddles
+        const TwFold<T> fpost(tw, post);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = twA_k(v[k], k, tw, fpost);
+    } else {
+        apply_twA(v, tw);
+    }
     dft16(v);
     SEQ_STAMP(10);  // twA + DFT#6
 }
@@ -248,6 +257,35 @@ __device__ constexpr double W32S16[16] = {0.0, 0.1950903220161282678482848684770
                                           0.70710678118654752440084436210485, 0.55557023301960222474283081394853,
                                           0.38268343236508977172845998403040, 0.19509032201612826784828486847702};
 
+// lo = e + w z, hi = e - w z for the compile-time constant w = W_32^i = c + i s, in 6 FMAs:
+// w z = c (z + i tau z), tau = s/c   (|c| >= |s|)   or   s (kappa z + i z), kappa = c/s.
+template <typename T>
+__device__ __forceinline__ void axpy_w32(int i, cpx<T> e, cpx<T> z, cpx<T> &lo, cpx<T> &hi)
+{
+    const double c = W32C16[i], s = W32S16[i];
+    cpx<T> b;
+    T g;
+    if (i == 0) {
+        b = z; g = T(1);
+    } else if (i == 8) {
+        b = muli(z); g = T(1);
+    } else if (c * c >= s * s) {
+        const T tau = (T)(s / c);
+        b = {vfma(-tau, z.y, z.x), vfma(tau, z.x, z.y)};
+        g = (T)c;
+    } else {
+        const T kap = (T)(c / s);
+        b = {vfma(kap, z.x, -z.y), vfma(kap, z.y, z.x)};
+        g = (T)s;
+    }
+    if (i == 0 || i == 8) {
+        lo = e + b; hi = e - b;
+    } else {
+        lo = {vfma(g, b.x, e.x), vfma(g, b.y, e.y)};
+        hi = {vfma(-g, b.x, e.x), vfma(-g, b.y, e.y)};
+    }
+}
+
 // STORE: 0 = 16-B write-through (sc1), 1 = 16-B plain, 2 = 16-B nontemporal, 3 = no surface store
 // (1-3 are measurement variants, selected with CAF_STORE_MODE; the product launches 0).
 // waves per SIMD the register allocator must leave room for: f64 rows need ~230 VGPRs (2),
@@ -282,6 +320,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
     const C cfac = conj(th);          // odd chain input rotation e^{-2*pi*i*t/8192}
     const int mpair = L.t & ~1;
     const bool odd = L.lane & 1;
+    constexpr unsigned long long EVEN_LANES = 0x5555555555555555ull;
     __syncthreads();
 
     unsigned long long st[S_NSTAMP] = {};
@@ -318,13 +357,13 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
         const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.spec + (size_t)b * (2 * 16 * 256)), 0, 2 * 16 * 256 * (int)sizeof(C), 0x00020000);
         C e[16], o[16];
-        seq_chain<T, 0, ABL, PF>(e, a, rs_sig, rs_spec, pb, ph + 32, tw, twB, Lc, L, st);
+        seq_chain<T, 0, ABL, PF>(e, a, rs_sig, rs_spec, pb, th, ph + 32, tw, twB, Lc, L, st);
         // the ticket was stored before the chain's barriers: visible to every wave by now
         const int gn = __builtin_amdgcn_readfirstlane(*next_row);
         const int gc = gn < A.total ? gn : A.total - 1;  // clamped: a[] is always redefined
         const __amdgpu_buffer_rsrc_t rs_sig_next = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
-        seq_chain<T, 1, ABL, PF>(o, a, rs_sig, rs_spec, cmul(pb, cfac), ph + 48, tw, twB, Lc, L, st);
+        seq_chain<T, 1, ABL, PF>(o, a, rs_sig, rs_spec, cmul(pb, cfac), th, ph + 48, tw, twB, Lc, L, st);
 
         // ---- last radix-2 stage (in registers) + |.|^2 + argmax + 16-B write-through stores --
         T bv_lo = T(0), bv_hi = T(0);
@@ -339,12 +378,14 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
         T mlo[16], mhi[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {  // m = t + 256*i
-            const C w32 = {(T)W32C16[i], (T)W32S16[i]};
-            const C z = cmul(cmul(o[i], th), w32);  // T^m * O[m]
-            mlo[i] = norm_sqr(e[i] + z);            // mod.rs:147
-            mhi[i] = norm_sqr(e[i] - z);
-            if (mlo[i] > bv_lo) { bv_lo = mlo[i]; bi_lo = i; }
-            if (mhi[i] > bv_hi) { bv_hi = mhi[i]; bi_hi = i; }
+            C lo, hi;  // E[m] +- W_32^i * (T^t O[m]); T^t came folded into the odd chain's last twiddles
+            axpy_w32(i, e[i], o[i], lo, hi);
+            mlo[i] = norm_sqr(lo);  // mod.rs:147
+            mhi[i] = norm_sqr(hi);
+            bi_lo = mlo[i] > bv_lo ? i : bi_lo;  // first strictly greater (mod.rs:148-151)
+            bv_lo = vmax(bv_lo, mlo[i]);         // one v_max instead of a 64-bit select
+            bi_hi = mhi[i] > bv_hi ? i : bi_hi;
+            bv_hi = vmax(bv_hi, mhi[i]);
             if constexpr (PF & 8)
                 a[i] = bload(rs_sig_next, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * i * sizeof(C)), (C *)nullptr);
         }
@@ -352,17 +393,26 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
             const C *phn = phasor + (size_t)(gc % A.rows) * 64;
             pb = cmul(phn[L.lo4], phn[16 + L.hi4]);
         }
+        if constexpr (STORE == 4) {  // one element per lane and store: no cross-lane pairing work
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const T slo = dpp_xor1<T>(odd ? mlo[2 * j] : mlo[2 * j + 1]);
-            const T shi = dpp_xor1<T>(odd ? mhi[2 * j] : mhi[2 * j + 1]);
-            const int m = mpair + 256 * (2 * j + (odd ? 1 : 0));
-            if constexpr (STORE != 3) {
-                constexpr int AUX = STORE == 0 ? CAF_AUX_SC1 : STORE == 2 ? 2 : 0;
-                store_pair_aux<AUX>(rs, (unsigned)(m * sizeof(T)), odd ? slo : mlo[2 * j], odd ? mlo[2 * j + 1] : slo);
-                store_pair_aux<AUX>(rs, (unsigned)((m + F_N) * sizeof(T)), odd ? shi : mhi[2 * j], odd ? mhi[2 * j + 1] : shi);
-            } else {
-                asm volatile("" ::"v"(slo), "v"(shi));
+            for (int i = 0; i < 16; ++i) {
+                store_one_aux<CAF_AUX_SC1>(rs, (unsigned)(L.t * sizeof(T)), (unsigned)(256 * i * sizeof(T)), mlo[i]);
+                store_one_aux<CAF_AUX_SC1>(rs, (unsigned)(L.t * sizeof(T)), (unsigned)((256 * i + F_N) * sizeof(T)), mhi[i]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                typename pair_vec<T>::type dlo, dhi;
+                pair_xor1(mlo[2 * j], mlo[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dlo);
+                pair_xor1(mhi[2 * j], mhi[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dhi);
+                const int m = mpair + 256 * (2 * j + (odd ? 1 : 0));
+                if constexpr (STORE != 3) {
+                    constexpr int AUX = STORE == 0 ? CAF_AUX_SC1 : STORE == 2 ? 2 : 0;
+                    store_vec_aux<AUX>(rs, (unsigned)(m * sizeof(T)), dlo);
+                    store_vec_aux<AUX>(rs, (unsigned)((m + F_N) * sizeof(T)), dhi);
+                } else {
+                    asm volatile("" ::"v"(dlo), "v"(dhi));
+                }
             }
         }
         T bv = bv_lo;
