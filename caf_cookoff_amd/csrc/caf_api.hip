@@ -565,6 +565,7 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
         case 12: k_seq_rows<T, 0, 2, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no global loads
         case 13: k_seq_rows<T, 3, 3, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // VALU only
         case 20: k_seq_rows<T, 0, 0, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;   // no software pipelining
+        case 21: k_seq_rows<T, 0, 0, 31><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // deferred argmax publish
         default: k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         }
     } else {

@@ -34,12 +34,89 @@ __device__ __forceinline__ cpx<T> cmulc(cpx<T> a, cpx<T> b)
     return {a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
 }
 template <typename T>
+__device__ __forceinline__ cpx<T> cmul_conj(cpx<T> a, cpx<T> b) { return {a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x)}; }
+template <typename T>
 __device__ __forceinline__ cpx<T> conj(cpx<T> a) { return {a.x, -a.y}; }
+// a + i b, a - i b
+template <typename T>
+__device__ __forceinline__ cpx<T> add_i(cpx<T> a, cpx<T> b) { return {a.x - b.y, a.y + b.x}; }
+template <typename T>
+__device__ __forceinline__ cpx<T> sub_i(cpx<T> a, cpx<T> b) { return {a.x + b.y, a.y - b.x}; }
 // i*a
 template <typename T>
 __device__ __forceinline__ cpx<T> muli(cpx<T> a) { return {-a.y, a.x}; }
 template <typename T>
 __device__ __forceinline__ T norm_sqr(cpx<T> a) { return a.x * a.x + a.y * a.y; }  // mod.rs:147
+
+// ---- packed-f32 forms (complex64 path) -------------------------------------------------------
+// A cpx<float> lives in an even-aligned VGPR pair, and gfx950's v_pk_{add,mul,fma}_f32 process
+// both halves in one issue slot.  The compiler selects them for plain element-wise arithmetic and
+// for broadcasts, but not for operands whose halves are SWAPPED (the cross terms of a complex
+// multiply, multiplication by +-i): it builds the swapped pair with v_xor + v_mov instead.  The
+// overloads below spell those with op_sel/op_sel_hi/neg_lo/neg_hi:
+//   op_sel[i]    = which half of source i feeds the LOW  result (0 = .x, 1 = .y), default 0
+//   op_sel_hi[i] = which half of source i feeds the HIGH result,                   default 1
+typedef float caf_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ caf_v2f pk(cpx<float> a) { return caf_v2f{a.x, a.y}; }
+__device__ __forceinline__ cpx<float> unpk(caf_v2f v) { return {v.x, v.y}; }
+
+__device__ __forceinline__ cpx<float> operator+(cpx<float> a, cpx<float> b) { return unpk(pk(a) + pk(b)); }
+__device__ __forceinline__ cpx<float> operator-(cpx<float> a, cpx<float> b) { return unpk(pk(a) - pk(b)); }
+
+// a + i b  and  a - i b: one v_pk_add_f32 each
+__device__ __forceinline__ cpx<float> add_i(cpx<float> a, cpx<float> b)
+{
+    caf_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(pk(a)), "v"(pk(b)));
+    return unpk(r);
+}
+__device__ __forceinline__ cpx<float> sub_i(cpx<float> a, cpx<float> b)
+{
+    caf_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(pk(a)), "v"(pk(b)));
+    return unpk(r);
+}
+// a*b: (a.x b.x, a.x b.y) then + a.y * (-b.y, b.x)
+__device__ __forceinline__ cpx<float> cmul(cpx<float> a, cpx<float> b)
+{
+    const caf_v2f av = pk(a), bv = pk(b), t = av.xx * bv;
+    caf_v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+    return unpk(r);
+}
+// a*conj(b): (a.x b.x, -a.x b.y) then + a.y * (b.y, b.x)
+__device__ __forceinline__ cpx<float> cmulc(cpx<float> a, cpx<float> b)
+{
+    const caf_v2f av = pk(a), bv = pk(b), t = av.xx * caf_v2f{bv.x, -bv.y};
+    caf_v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+    return unpk(r);
+}
+// conj(a*b): (a.x b.x, -a.x b.y) then + a.y * (-b.y, -b.x)
+__device__ __forceinline__ cpx<float> cmul_conj(cpx<float> a, cpx<float> b)
+{
+    const caf_v2f av = pk(a), bv = pk(b), t = av.xx * caf_v2f{bv.x, -bv.y};
+    caf_v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
+        : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+    return unpk(r);
+}
+// v + r (i v)  and  r v + i v  (the Linzer-Feig pre-rotations of bfly_w)
+__device__ __forceinline__ cpx<float> lf_tan(cpx<float> v, float r)
+{
+    caf_v2f o;
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]"
+        : "=v"(o) : "v"(caf_v2f{r, r}), "v"(pk(v)));
+    return unpk(o);
+}
+__device__ __forceinline__ cpx<float> lf_cot(cpx<float> v, float r)
+{
+    caf_v2f o;
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[0,1,0] neg_lo:[0,0,1]"
+        : "=v"(o) : "v"(caf_v2f{r, r}), "v"(pk(v)));
+    return unpk(o);
+}
 
 __device__ __forceinline__ double vfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

@@ -82,11 +82,11 @@ __global__ void k_fused_phasors(const double *__restrict__ ph, int nrows, cpx<T>
 template <typename T>
 __device__ __forceinline__ void dft4(cpx<T> &a, cpx<T> &b, cpx<T> &c, cpx<T> &d)
 {
-    const cpx<T> apc = a + c, amc = a - c, bpd = b + d, jbmd = muli(b - d);
-    a = apc + bpd;   // X0
-    b = amc + jbmd;  // X1 = x0 + i x1 - x2 - i x3
-    c = apc - bpd;   // X2
-    d = amc - jbmd;  // X3
+    const cpx<T> apc = a + c, amc = a - c, bpd = b + d, bmd = b - d;
+    a = apc + bpd;        // X0
+    b = add_i(amc, bmd);  // X1 = x0 + i x1 - x2 - i x3
+    c = apc - bpd;        // X2
+    d = sub_i(amc, bmd);  // X3
 }
 
 template <typename T>
@@ -105,27 +105,90 @@ __device__ __forceinline__ cpx<T> mul_w8_3(cpx<T> a)  // * e^{i*3*pi/4}
 template <typename T>
 __device__ __forceinline__ void swp(cpx<T> &a, cpx<T> &b) { const cpx<T> t = a; a = b; b = t; }
 
+// v + r (i v) and r v + i v
+template <typename T>
+__device__ __forceinline__ cpx<T> lf_tan(cpx<T> v, T r) { return {vfma(-r, v.y, v.x), vfma(r, v.x, v.y)}; }
+template <typename T>
+__device__ __forceinline__ cpx<T> lf_cot(cpx<T> v, T r) { return {vfma(r, v.x, -v.y), vfma(r, v.y, v.x)}; }
+// p = u + g b, m = u - g b for a real g
+template <typename T>
+__device__ __forceinline__ void axpy_pm(T g, cpx<T> b, cpx<T> u, cpx<T> &p, cpx<T> &m)
+{
+    p = {vfma(g, b.x, u.x), vfma(g, b.y, u.y)};
+    m = {vfma(-g, b.x, u.x), vfma(-g, b.y, u.y)};
+}
+__device__ __forceinline__ void axpy_pm(float g, cpx<float> b, cpx<float> u, cpx<float> &p, cpx<float> &m)
+{
+    const caf_v2f gg = {g, g}, bv = pk(b), uv = pk(u);
+    p = unpk(__builtin_elementwise_fma(gg, bv, uv));
+    m = unpk(__builtin_elementwise_fma(-gg, bv, uv));
+}
+
+// p = u + w v, m = u - w v for a unit constant w = c + i s known at compile time (after
+// inlining), in six FMAs instead of a complex multiply + two complex adds (Linzer-Feig):
+//   w v = g b,  g = c, b = v + i (s/c) v   if |c| >= |s|;   g = s, b = (c/s) v + i v   otherwise.
+template <typename T>
+__device__ __forceinline__ void bfly_w(cpx<T> u, cpx<T> v, double c, double s, cpx<T> &p, cpx<T> &m)
+{
+    if (s == 0.0) {  // w = +-1
+        p = c < 0.0 ? u - v : u + v;
+        m = c < 0.0 ? u + v : u - v;
+        return;
+    }
+    if (c == 0.0) {  // w = +-i
+        p = s < 0.0 ? sub_i(u, v) : add_i(u, v);
+        m = s < 0.0 ? add_i(u, v) : sub_i(u, v);
+        return;
+    }
+    cpx<T> b;
+    T g;
+    if (c * c >= s * s) {
+        b = lf_tan(v, (T)(s / c));
+        g = (T)c;
+    } else {
+        b = lf_cot(v, (T)(c / s));
+        g = (T)s;
+    }
+    axpy_pm(g, b, u, p, m);
+}
+
+// dft4 of (a, w1 b, w2 c, w3 d) for unit constants with w3 = w1 * wr:  24 FMAs (20 when w2 and
+// wr are +-i) instead of three complex multiplies + 16 adds.
+template <typename T>
+__device__ __forceinline__ void dft4_w(cpx<T> &a, cpx<T> &b, cpx<T> &c, cpx<T> &d, double c1, double s1, double c2,
+                                       double s2, double cr, double sr)
+{
+    cpx<T> p, m, r, q;
+    bfly_w(a, c, c2, s2, p, m);
+    bfly_w(b, d, cr, sr, r, q);
+    bfly_w(p, r, c1, s1, a, c);   // X0, X2
+    bfly_w(m, q, -s1, c1, b, d);  // X1, X3 = m +- i w1 q
+}
+
+// second radix-4 stage of the 16-point butterfly for residue r0: inputs v[4 r0 + j] carry the
+// constant twiddles W_16^(r0 j), folded into the butterflies
+template <typename T>
+__device__ __forceinline__ void dft16_stage2(cpx<T> (&v)[16], int r0)
+{
+    constexpr double C1 = 0.92387953251128675612818318939679;  // cos(pi/8)
+    constexpr double S1 = 0.38268343236508977172845998403040;  // sin(pi/8)
+    constexpr double R = 0.70710678118654752440084436210485;
+    cpx<T> &a = v[4 * r0], &b = v[4 * r0 + 1], &c = v[4 * r0 + 2], &d = v[4 * r0 + 3];
+    if (r0 == 0) dft4(a, b, c, d);
+    if (r0 == 1) dft4_w(a, b, c, d, C1, S1, R, R, R, R);          // W16^1, W16^2, W16^3 = W16^1 W16^2
+    if (r0 == 2) dft4_w(a, b, c, d, R, R, 0.0, 1.0, 0.0, 1.0);    // W16^2, W16^4, W16^6 = W16^2 W16^4
+    if (r0 == 3) dft4_w(a, b, c, d, S1, C1, -R, R, -R, R);        // W16^3, W16^6, W16^9 = W16^3 W16^6
+}
+
 template <typename T>
 __device__ __forceinline__ void dft16(cpx<T> (&v)[16])
 {
-    const T c1 = T(0.92387953251128675612818318939679);  // cos(pi/8)
-    const T s1 = T(0.38268343236508977172845998403040);  // sin(pi/8)
     // stage 1: over q1 for each q0 (inputs v[q0 + 4*q1]) -> a[r0;q0] at v[q0 + 4*r0]
 #pragma unroll
     for (int q0 = 0; q0 < 4; ++q0) dft4(v[q0], v[q0 + 4], v[q0 + 8], v[q0 + 12]);
-    // W16^(q0*r0)
-    v[5] = cmul(v[5], cpx<T>{c1, s1});     // e=1
-    v[9] = mul_w8(v[9]);                   // e=2
-    v[13] = cmul(v[13], cpx<T>{s1, c1});   // e=3
-    v[6] = mul_w8(v[6]);                   // e=2
-    v[10] = muli(v[10]);                   // e=4
-    v[14] = mul_w8_3(v[14]);               // e=6
-    v[7] = cmul(v[7], cpx<T>{s1, c1});     // e=3
-    v[11] = mul_w8_3(v[11]);               // e=6
-    v[15] = cmul(v[15], cpx<T>{-c1, -s1}); // e=9
-    // stage 2: over q0 for each r0 -> X[r0 + 4*r1] at v[4*r0 + r1]
+    // stage 2 (with the W16^(q0*r0) twiddles): over q0 for each r0 -> X[r0 + 4*r1] at v[4*r0 + r1]
 #pragma unroll
-    for (int r0 = 0; r0 < 4; ++r0) dft4(v[4 * r0], v[4 * r0 + 1], v[4 * r0 + 2], v[4 * r0 + 3]);
+    for (int r0 = 0; r0 < 4; ++r0) dft16_stage2(v, r0);
     // 4x4 transpose of the register names -> X[k] at v[k]
     swp(v[1], v[4]); swp(v[2], v[8]); swp(v[3], v[12]);
     swp(v[6], v[9]); swp(v[7], v[13]); swp(v[11], v[14]);
@@ -139,22 +202,11 @@ __device__ __forceinline__ void dft16(cpx<T> (&v)[16])
 template <typename T, typename F>
 __device__ __forceinline__ void dft16_sink(cpx<T> (&v)[16], F &&sink)
 {
-    const T c1 = T(0.92387953251128675612818318939679);
-    const T s1 = T(0.38268343236508977172845998403040);
 #pragma unroll
     for (int q0 = 0; q0 < 4; ++q0) dft4(v[q0], v[q0 + 4], v[q0 + 8], v[q0 + 12]);
-    v[5] = cmul(v[5], cpx<T>{c1, s1});
-    v[9] = mul_w8(v[9]);
-    v[13] = cmul(v[13], cpx<T>{s1, c1});
-    v[6] = mul_w8(v[6]);
-    v[10] = muli(v[10]);
-    v[14] = mul_w8_3(v[14]);
-    v[7] = cmul(v[7], cpx<T>{s1, c1});
-    v[11] = mul_w8_3(v[11]);
-    v[15] = cmul(v[15], cpx<T>{-c1, -s1});
 #pragma unroll
     for (int r0 = 0; r0 < 4; ++r0) {
-        dft4(v[4 * r0], v[4 * r0 + 1], v[4 * r0 + 2], v[4 * r0 + 3]);  // X[r0 + 4*r1] at v[4*r0 + r1]
+        dft16_stage2(v, r0);  // X[r0 + 4*r1] at v[4*r0 + r1]
 #pragma unroll
         for (int r1 = 0; r1 < 4; ++r1) sink(r0 + 4 * r1, v[4 * r0 + r1]);
     }

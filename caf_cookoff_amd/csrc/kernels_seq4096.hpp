@@ -24,7 +24,7 @@ namespace caf {
 constexpr int S_THREADS = 256;
 
 template <typename T>
-constexpr size_t seq_lds_bytes() { return (F_CHAIN + 256) * sizeof(cpx<T>) + 64; }  // +64: argmax scratch, next-row word
+constexpr size_t seq_lds_bytes() { return (F_CHAIN + 256) * sizeof(cpx<T>) + 128; }  // +128: two argmax slots, next-row word
 
 struct SeqLane {
     int tid, lane, wave, t, hi4, lo4, pA, pB, pC;
@@ -57,6 +57,8 @@ __device__ __forceinline__ void keep(cpx<T> &x)
 //   2: odd chain  - needle samples loaded during the even chain's last pass
 //   4: odd chain  - haystack-spectrum loads issued before pass 3
 //   8: even chain - the NEXT row's needle samples loaded while the epilogue retires registers
+//  16: (not a load) publish a row's argmax after the next row's first barriers instead of
+//      behind a barrier of its own
 template <typename T>
 __device__ __forceinline__ void load_samples(cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t rs_sig, const SeqLane &L)
 {
@@ -67,7 +69,7 @@ __device__ __forceinline__ void load_samples(cpx<T> (&a)[16], const __amdgpu_buf
 }
 
 // ABL bit 3: s_memtime stamps (diagnostic build, tools/stamps_seq.py)
-constexpr int S_NSTAMP = 24;
+constexpr int S_NSTAMP = 28;
 #define SEQ_STAMP(i)                                                                             \
     if constexpr (ABL & 8) {                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                       \
@@ -98,7 +100,7 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
 #pragma unroll
         // conj(a * w^t * step[q]) = conj(a * step[q]) * conj(w^t): the lane factor conj(w^t)
         // commutes with the first butterfly and is folded into its output twiddles (TwFold)
-        for (int q = 0; q < 16; ++q) v[q] = conj(cmul(a[q], ps[q]));
+        for (int q = 0; q < 16; ++q) v[q] = cmul_conj(a[q], ps[q]);
     }
     const TwFold<T> fmix(tw, conj(pb));
     if constexpr (H_EARLY) {
@@ -262,28 +264,7 @@ __device__ constexpr double W32S16[16] = {0.0, 0.1950903220161282678482848684770
 template <typename T>
 __device__ __forceinline__ void axpy_w32(int i, cpx<T> e, cpx<T> z, cpx<T> &lo, cpx<T> &hi)
 {
-    const double c = W32C16[i], s = W32S16[i];
-    cpx<T> b;
-    T g;
-    if (i == 0) {
-        b = z; g = T(1);
-    } else if (i == 8) {
-        b = muli(z); g = T(1);
-    } else if (c * c >= s * s) {
-        const T tau = (T)(s / c);
-        b = {vfma(-tau, z.y, z.x), vfma(tau, z.x, z.y)};
-        g = (T)c;
-    } else {
-        const T kap = (T)(c / s);
-        b = {vfma(kap, z.x, -z.y), vfma(kap, z.y, z.x)};
-        g = (T)s;
-    }
-    if (i == 0 || i == 8) {
-        lo = e + b; hi = e - b;
-    } else {
-        lo = {vfma(g, b.x, e.x), vfma(g, b.y, e.y)};
-        hi = {vfma(-g, b.x, e.x), vfma(-g, b.y, e.y)};
-    }
+    bfly_w(e, z, W32C16[i], W32S16[i], lo, hi);
 }
 
 // STORE: 0 = 16-B write-through (sc1), 1 = 16-B plain, 2 = 16-B nontemporal, 3 = no surface store
@@ -339,7 +320,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
     // to 30 % apart (per-CU clock/L2 effects, profiles/r01_v3 notes); with tickets they all end
     // within one row time.  Tickets are in surface-major order, so at any moment the whole chip
     // works on 1-2 surfaces and their inputs stay L2-resident, as with static striding.
-    volatile int *const next_row = reinterpret_cast<volatile int *>(scratch + 48);
+    volatile int *const next_row = reinterpret_cast<volatile int *>(scratch + 112);
     // phasor base w^t of the first row (later rows: fetched in the previous row's epilogue)
     C pb;
     {
@@ -347,6 +328,20 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
         const C *ph0 = phasor + (size_t)(g0 % A.rows) * 64;
         pb = cmul(ph0[L.lo4], ph0[16 + L.hi4]);
     }
+    int prev_g = -1, parity = 0;
+    // Per-wave argmax partials go to scratch slot `parity`; they are merged into the row's result
+    // after the NEXT row's first two barriers (or after the loop), so a row needs no barrier of
+    // its own for that.
+    auto publish = [&](int row, int slot) {
+        const T *sv = reinterpret_cast<const T *>(scratch + slot * 64);
+        const uint32_t *si = reinterpret_cast<const uint32_t *>(scratch + slot * 64 + 32);
+        T bv = sv[0];
+        uint32_t bi = si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) arg_merge(bv, bi, sv[w], si[w]);
+        A.row_idx[row] = bi;
+        A.row_val[row] = bv;
+    };
     for (int g = blockIdx.x; g < A.total;) {
         if (L.tid == 0)
             *next_row = A.work ? (int)gridDim.x + (int)atomicAdd(A.work, 1u) : g + (int)gridDim.x;
@@ -360,6 +355,9 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
         seq_chain<T, 0, ABL, PF>(e, a, rs_sig, rs_spec, pb, th, ph + 32, tw, twB, Lc, L, st);
         // the ticket was stored before the chain's barriers: visible to every wave by now
         const int gn = __builtin_amdgcn_readfirstlane(*next_row);
+        if constexpr (PF & 16) {
+            if (L.tid == 0 && prev_g >= 0) publish(prev_g, parity ^ 1);
+        }
         const int gc = gn < A.total ? gn : A.total - 1;  // clamped: a[] is always redefined
         const __amdgpu_buffer_rsrc_t rs_sig_next = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
@@ -389,6 +387,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
             if constexpr (PF & 8)
                 a[i] = bload(rs_sig_next, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * i * sizeof(C)), (C *)nullptr);
         }
+        if constexpr (ABL & 8) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[23])::"memory"); __builtin_amdgcn_sched_barrier(0); }
         {   // phasor base of the next row
             const C *phn = phasor + (size_t)(gc % A.rows) * 64;
             pb = cmul(phn[L.lo4], phn[16 + L.hi4]);
@@ -415,23 +414,23 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
                 }
             }
         }
+        if constexpr (ABL & 8) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[24])::"memory"); __builtin_amdgcn_sched_barrier(0); }
         T bv = bv_lo;
         uint32_t bi = bv_lo > T(0) ? (uint32_t)(L.t + 256 * bi_lo) : 0u;
         if (bv_hi > bv) { bv = bv_hi; bi = (uint32_t)(L.t + 256 * bi_hi + F_N); }
         wave_arg_reduce_dpp(bv, bi);
-        T *sv = reinterpret_cast<T *>(scratch);
-        uint32_t *si = reinterpret_cast<uint32_t *>(scratch + 32);
-        if (L.lane == 63) { sv[L.wave] = bv; si[L.wave] = bi; }
-        __syncthreads();
-        if (L.tid == 0) {
-            bv = sv[0];
-            bi = si[0];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) arg_merge(bv, bi, sv[w], si[w]);
-            A.row_idx[g] = bi;
-            A.row_val[g] = bv;
+        {
+            T *sv = reinterpret_cast<T *>(scratch + parity * 64);
+            uint32_t *si = reinterpret_cast<uint32_t *>(scratch + parity * 64 + 32);
+            if (L.lane == 63) { sv[L.wave] = bv; si[L.wave] = bi; }
         }
-        // scratch is rewritten only after the next row's six barriers: no extra barrier needed
+        if constexpr (PF & 16) {
+            prev_g = g;
+            parity ^= 1;
+        } else {  // publish now: one more barrier per row, which also re-aligns the four waves
+            __syncthreads();
+            if (L.tid == 0) publish(g, 0);
+        }
         if constexpr (ABL & 8) {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[22])::"memory");
@@ -442,6 +441,10 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
             ++iter;
         }
         g = gn;
+    }
+    if constexpr (PF & 16) {
+        __syncthreads();  // last row's partials
+        if (L.tid == 0 && prev_g >= 0) publish(prev_g, parity ^ 1);
     }
     if constexpr (ABL & 8) {
         unsigned long long wg_t1;

@@ -11,7 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import caf_cookoff_amd as caf  # noqa: E402
 from caf_cookoff_amd.synth import make_batch  # noqa: E402
 
-NST = 24
+NST = 28
 SEG = ["mixer(+a wait)", "DFT1+twA+ex1 W", "barrier ex1", "ex1 R+DFT2+twB+ex2 W", "ex2 R+DFT3", "H mul+DFT4+ex3 W",
        "ex3 R+twB+DFT5+ex4 W", "barrier ex4", "ex4 R+barrier", "twA+DFT6"]
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
@@ -62,6 +62,9 @@ for ch in (0, 1):
         print(f"  chain E->O gap               {gap:8.0f}  {100 * gap / tot:5.1f}%")
 ep = (d[:, :, 22] - d[:, :, 21]).mean()
 print(f"  epilogue (combine/stores/argmax) {ep:6.0f}  {100 * ep / tot:5.1f}%")
+for name, a, b in (("    last stage + |.|^2 + next-row loads", 21, 23), ("    pairing + stores", 23, 24), ("    argmax reduce + publish", 24, 22)):
+    seg = (d[:, :, b] - d[:, :, a]).mean()
+    print(f"  {name:40s} {seg:6.0f}  {100 * seg / tot:5.1f}%")
 
 # ---- wall time of the stamped build vs the normal build (same data) ----
 def timeit(n=20):
