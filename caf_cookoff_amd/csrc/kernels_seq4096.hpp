@@ -269,10 +269,11 @@ __device__ __forceinline__ void axpy_w32(int i, cpx<T> e, cpx<T> z, cpx<T> &lo, 
 
 // STORE: 0 = 16-B write-through (sc1), 1 = 16-B plain, 2 = 16-B nontemporal, 3 = no surface store
 // (1-3 are measurement variants, selected with CAF_STORE_MODE; the product launches 0).
-// waves per SIMD the register allocator must leave room for: f64 rows need ~230 VGPRs (2),
-// f32 rows fit 168 (3 workgroups of 36 KiB LDS per CU; 128 VGPRs would spill 96)
+// waves per SIMD the register allocator must leave room for: f64 rows need 256 VGPRs (2; LDS
+// allows no more anyway); the packed-f32 rows fit 168 without spills (3 workgroups of 36 KiB LDS
+// per CU: 108.6 k surfaces/s vs 103.5 k at 2 x 216 VGPRs and 102.8 k at 4 x 128 with 31 spills)
 template <typename T>
-constexpr int seq_waves_per_simd() { return sizeof(T) == 8 ? 2 : 2; }
+constexpr int seq_waves_per_simd() { return sizeof(T) == 8 ? 2 : 3; }
 
 // `phasor` is passed as its own __restrict__ parameter (not inside FusedArgs) so that the
 // wave-uniform step entries become scalar loads: they cost no vector-memory issue slot and,
