@@ -560,11 +560,17 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
         case 1: k_seq_rows<T, 1><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         case 2: k_seq_rows<T, 2><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         case 3: k_seq_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
+        case 5: k_seq_rows<T, 5><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         case 4: k_seq_rows<T, 4><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         case 11: k_seq_rows<T, 0, 1, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS
         case 12: k_seq_rows<T, 0, 2, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no global loads
         case 13: k_seq_rows<T, 3, 3, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // VALU only
         case 20: k_seq_rows<T, 0, 0, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;   // no software pipelining
+        case 31: k_seq_rows<T, 0, 1, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS, pipelined loads
+        case 32: k_seq_rows<T, 0, 2, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no global loads
+        case 33: k_seq_rows<T, 3, 3, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // VALU only
+        case 34: k_seq_rows<T, 3, 1, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS, no stores
+        case 35: k_seq_rows<T, 3, 2, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no loads, no stores
         case 21: k_seq_rows<T, 0, 0, 31><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // deferred argmax publish
         default: k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         }

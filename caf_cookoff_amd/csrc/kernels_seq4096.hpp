@@ -367,7 +367,8 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
         // ---- last radix-2 stage (in registers) + |.|^2 + argmax + 16-B write-through stores --
         T bv_lo = T(0), bv_hi = T(0);
         int bi_lo = 0, bi_hi = 0;
-        T *const out = A.surface ? A.surface + (size_t)g * F_L : nullptr;
+        // STORE 5 (measurement, wrong results): every row of a workgroup lands on the same 64 KiB
+        T *const out = A.surface ? A.surface + (size_t)(STORE == 5 ? (int)blockIdx.x : g) * F_L : nullptr;
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? F_L * (int)sizeof(T) : 0, 0x00020000);
         // All magnitudes first; each retired (e[i], o[i]) pair frees the registers that receive the
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
                 pair_xor1(mhi[2 * j], mhi[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dhi);
                 const int m = mpair + 256 * (2 * j + (odd ? 1 : 0));
                 if constexpr (STORE != 3) {
-                    constexpr int AUX = STORE == 0 ? CAF_AUX_SC1 : STORE == 2 ? 2 : 0;
+                    constexpr int AUX = (STORE == 0 || STORE == 5) ? CAF_AUX_SC1 : STORE == 2 ? 2 : 0;
                     store_vec_aux<AUX>(rs, (unsigned)(m * sizeof(T)), dlo);
                     store_vec_aux<AUX>(rs, (unsigned)((m + F_N) * sizeof(T)), dhi);
                 } else {
