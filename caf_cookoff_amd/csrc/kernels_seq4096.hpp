@@ -4,18 +4,22 @@
 // 256-thread workgroup (4 waves, one per SIMD) owns a row and runs the EVEN-bin chain and
 // then the ODD-bin chain in the same threads:
 //   * LDS per workgroup = ONE padded chain (4352 complex) + the 256-entry W_256 table
-//     = 72.3 KiB (f64), so TWO workgroups are resident per CU.  They share nothing and hit
-//     their barriers independently: while one sits in an LDS exchange (write-limited,
-//     ~79 B/clk/CU) or waits on L2, the other has the VALU.  In the 512-thread kernel all 8
-//     waves are in the same phase and the two pipes run serially (profiles/r01_*).
+//     = 72.3 KiB (f64) / 36.2 KiB (f32), so TWO (f64) or THREE (f32, 168 VGPRs) workgroups are
+//     resident per CU.  They share nothing and hit their barriers independently: while one
+//     sits in an LDS exchange or waits on L2, the other has the VALU.  In the 512-thread
+//     kernel all 8 waves are in the same phase and the two pipes run serially (profiles/r01_*).
 //   * both chain outputs E[m], O[m] of a thread are in its own registers, so the last
 //     radix-2 stage needs no cross-lane traffic at all.
 //   * register budget: 64 (v) + 64 (E stash) + twiddles.  Only W^(t), W^(2t), W^(3t), W^(4t),
 //     W^(8t), W^(12t) are held (24 VGPRs); the other nine W^(t(4a+b)) = W^(4at) W^(bt) cost one
 //     extra complex multiply each per use (+4 % VALU).
+//   * lane-wide common factors (the mixer's w^t, the odd chain's T^t) ride on the stage
+//     twiddles (TwFold); compile-time twiddles are folded into 6-FMA butterflies (bfly_w).
 //   * input loads are software-pipelined (PF bits below), LDS writes of each exchange are
 //     issued group by group from the last butterfly stage (dft16_sink), rows are handed out
-//     by a device-scope ticket counter.
+//     by a device-scope ticket counter (static stride for launches of <= 4 rows/workgroup).
+//   * 5 workgroup barriers per row (2 per chain + the argmax publication, which also re-aligns
+//     the waves); the other four exchanges are wave-local.
 #pragma once
 #include "kernels_fused4096.hpp"
 

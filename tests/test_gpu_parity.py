@@ -338,6 +338,49 @@ def test_batch_of_all_kat_pairs_ticket_path(eng, oracle, golden):
     plan.close()
 
 
+def test_ragged_shard_batches_both_row_assignments(eng, oracle):
+    """Odd row shard (rows 13..390 of the 400) with 9 surfaces (3393 rows: ticket path) and with
+    2 surfaces (754 rows: static stride), complex128 and complex64: every surface must equal the
+    one-surface call of the same plan bit for bit, and the c128 argmax rows the numpy oracle."""
+    import torch
+    fr = oracle.bench_shifts()
+    pairs = [_pair(oracle, k) for k in range(9)]
+    for dtype, tdt, cdt in (("c128", torch.float64, np.complex128), ("c64", torch.float32, np.complex64)):
+        nd = torch.from_numpy(np.stack([p[0] for p in pairs]).astype(cdt)).cuda()
+        hs = torch.from_numpy(np.stack([p[1] for p in pairs]).astype(cdt)).cuda()
+        plan = eng.plan(4096, fr, FS, dtype=dtype, row_begin=13, row_end=390)
+        rows = plan.rows
+        assert rows == 377
+        one_s = torch.empty((1, rows, 8192), dtype=tdt, device="cuda")
+        one_i = torch.empty((1, rows), dtype=torch.int64, device="cuda")
+        one_v = torch.empty((1, rows), dtype=tdt, device="cuda")
+        one_p = torch.empty((1, 4), dtype=torch.float64, device="cuda")
+        singles = []
+        for b in range(9):
+            plan.surface_dev(nd[b].data_ptr(), hs[b].data_ptr(), 1, one_s.data_ptr(), one_i.data_ptr(),
+                             one_v.data_ptr(), one_p.data_ptr())
+            eng.synchronize()
+            singles.append((one_s[0].clone(), one_i[0].clone(), one_v[0].clone(), one_p[0].clone()))
+        for batch in (9, 2):
+            surf = torch.full((batch, rows, 8192), -1.0, dtype=tdt, device="cuda")
+            ridx = torch.empty((batch, rows), dtype=torch.int64, device="cuda")
+            rval = torch.empty((batch, rows), dtype=tdt, device="cuda")
+            peak = torch.empty((batch, 4), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            plan.surface_dev(nd.data_ptr(), hs.data_ptr(), batch, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(),
+                             peak.data_ptr())
+            eng.synchronize()
+            for b in range(batch):
+                s1, i1, v1, p1 = singles[b]
+                assert torch.equal(surf[b], s1) and torch.equal(ridx[b], i1) and torch.equal(rval[b], v1)
+                assert torch.equal(peak[b], p1)
+        if dtype == "c128":
+            osurf, oidx, oval = oracle.np_caf_surface(pairs[3][0], pairs[3][1], fr[13:390], FS)
+            assert np.array_equal(singles[3][1].cpu().numpy().astype(np.uint64), oidx)
+            assert np.max(np.abs(singles[3][0].cpu().numpy() - osurf)) <= TOL64 * osurf.max()
+        plan.close()
+
+
 # ------------------------------------------------------------------ streaming --
 def test_streaming_double_buffer(eng, oracle, golden, manifest):
     """BASELINE configs[4] mechanics: pinned double-buffered H2D + one hipGraph per slot;
