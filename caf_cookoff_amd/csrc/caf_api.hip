@@ -15,6 +15,7 @@
 #include "../../include/caf_hip.h"
 #include "kernels_fused4096.hpp"
 #include "kernels_seq4096.hpp"
+#include "kernels_duo4096.hpp"
 #include "kernels_r8_4096.hpp"
 #include "kernels_big65536.hpp"
 #include "kernels_generic.hpp"
@@ -102,7 +103,7 @@ struct caf_plan {
     void *d_tw = nullptr;  // borrowed from ctx cache
     DevBuf wx, wy, hx, hy;
     unsigned long long *dbg = nullptr;  // diagnostic stamps buffer (caf_debug_set_stamps)
-    int variant = 0;                    // 0: sequential-chain row kernel, 1: 512-thread lane-half kernel
+    int variant = 0;                    // row kernel of n = 4096 plans: 0 sequential chains, 3 two chains in flight; 1, 2: measurement variants
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -389,6 +390,7 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     p->rows = row_end - row_begin;
     p->fused = (n == (size_t)F_N);
     p->big = (n == (size_t)B_N);
+    p->variant = dtype == CAF_C64 ? 3 : 0;  // f32: two chains in flight; f64: sequential chains (kernels_duo4096.hpp)
     if (const char *ev = getenv("CAF_ROW_KERNEL")) p->variant = atoi(ev);
     int rc = CAF_OK;
     auto bail = [&](int code) { caf_plan_destroy(p); return code; };
@@ -442,6 +444,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
     if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
     if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0, 15>" : "caf::k_seq_rows<float, 0, 0, 15>";
     if (p->variant == 2) return f64 ? "caf::k_r8_rows<double, 0>" : "caf::k_r8_rows<float, 0>";
+    if (p->variant == 3) return f64 ? "caf::k_duo_rows<double, 0>" : "caf::k_duo_rows<float, 0>";
     return f64 ? "caf::k_fused_rows<double, false>" : "caf::k_fused_rows<float, false>";
 }
 
@@ -542,6 +545,16 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
             k_r8_rows<T, 3><<<grid, R_THREADS, 0, c->stream>>>(a);
         else
             k_r8_rows<T, 0><<<grid, R_THREADS, 0, c->stream>>>(a);
+    } else if (p->variant == 3) {
+        size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
+        if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();
+        const size_t cap = (size_t)c->cu_count * per_cu;
+        const unsigned grid = (unsigned)(total < cap ? total : cap);
+        static const int duo_nostore = getenv("CAF_STORE_MODE") ? atoi(getenv("CAF_STORE_MODE")) == 3 : 0;
+        if (duo_nostore)
+            k_duo_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
+        else
+            k_duo_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
     } else if (p->variant == 0 && p->dbg) {
         size_t per_cu = 2;
         static const int wg_env = getenv("CAF_WG_PER_CU") ? atoi(getenv("CAF_WG_PER_CU")) : 0;

@@ -381,6 +381,43 @@ def test_ragged_shard_batches_both_row_assignments(eng, oracle):
         plan.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3], ids=["sequential", "lane-half", "radix8", "two-chain"])
+def test_row_kernel_variants_agree(variant, eng, oracle, golden, monkeypatch):
+    """All four n = 4096 row kernels (CAF_ROW_KERNEL) produce the reference's
+    answer: the product uses 0 for complex128 and 3 for complex64, the others are measurement
+    variants and must stay parity-green."""
+    monkeypatch.setenv("CAF_ROW_KERNEL", str(variant))
+    fr = oracle.bench_shifts()
+    nd, hs = _pair(oracle, 0)
+    for dtype, tol in (("c128", TOL64), ("c64", TOL32)):
+        plan = eng.plan(4096, fr, FS, dtype=dtype)
+        surf, ridx, rval, peak = _plan_arrays(plan, eng, nd, hs, dtype)
+        plan.close()
+        g = golden["bench0_row_val"]
+        assert (peak["freq"], int(peak["idx"])) == (69.0, 202)
+        assert np.max(np.abs(rval - g)) <= tol * g.max()
+        if dtype == "c128":
+            assert np.array_equal(ridx.astype(np.uint64), golden["bench0_row_idx"])
+
+
+def _plan_arrays(plan, eng, nd, hs, dtype):
+    import torch
+    import caf_cookoff_amd as caf
+    cdt, tdt = (np.complex128, torch.float64) if dtype == "c128" else (np.complex64, torch.float32)
+    d_nd = torch.from_numpy(nd.astype(cdt)[None]).cuda()
+    d_hs = torch.from_numpy(hs.astype(cdt)[None]).cuda()
+    surf = torch.empty((1, plan.rows, 8192), dtype=tdt, device="cuda")
+    ridx = torch.empty((1, plan.rows), dtype=torch.int64, device="cuda")
+    rval = torch.empty((1, plan.rows), dtype=tdt, device="cuda")
+    peak = torch.empty((1, 4), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    plan.surface_dev(d_nd.data_ptr(), d_hs.data_ptr(), 1, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(),
+                     peak.data_ptr())
+    eng.synchronize()
+    pk = peak.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[0, 0]
+    return surf[0].cpu().numpy(), ridx[0].cpu().numpy(), rval[0].cpu().numpy().astype(np.float64), pk
+
+
 # ------------------------------------------------------------------ streaming --
 def test_streaming_double_buffer(eng, oracle, golden, manifest):
     """BASELINE configs[4] mechanics: pinned double-buffered H2D + one hipGraph per slot;
