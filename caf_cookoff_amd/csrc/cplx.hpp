@@ -206,4 +206,61 @@ __device__ __forceinline__ void wave_arg_reduce_dpp(T &bv, uint32_t &bi)
     arg_step<T, 0x143, 0xC>(bv, bi);  // row_bcast31 into rows 2,3 -> lane 63 has the wave result
 }
 
+// Cheaper form of the same reduction: wave maximum of the values first (v_max through the DPP
+// network), then the minimum index among the lanes that hold it (v_min_u32 with a DPP operand).
+// Equal values keep the LOWER index, like arg_merge.  Lane 63 holds the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void max_step(double &v)
+{   // (asm: llvm.maxnum would first canonicalise the bit-cast DPP result with a second v_max)
+    const double o = dpp_t<CTRL, ROW_MASK>(v);
+    asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void max_step(float &v)
+{
+    const float o = dpp_t<CTRL, ROW_MASK>(v);
+    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void min_step(uint32_t &i)
+{
+    const uint32_t o = (uint32_t)dpp_i<CTRL, ROW_MASK>((int)i);
+    i = o < i ? o : i;
+}
+template <typename T>
+__device__ __forceinline__ T lane63(T v);
+template <>
+__device__ __forceinline__ double lane63<double>(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <>
+__device__ __forceinline__ float lane63<float>(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <typename T>
+__device__ __forceinline__ void wave_arg_reduce_maxmin(T &bv, uint32_t &bi)
+{
+    T m = bv;
+    max_step<0xB1, 0xF>(m);
+    max_step<0x4E, 0xF>(m);
+    max_step<0x141, 0xF>(m);
+    max_step<0x140, 0xF>(m);
+    max_step<0x142, 0xA>(m);
+    max_step<0x143, 0xC>(m);
+    m = lane63(m);  // wave-uniform
+    uint32_t c = bv == m ? bi : 0xffffffffu;
+    min_step<0xB1, 0xF>(c);
+    min_step<0x4E, 0xF>(c);
+    min_step<0x141, 0xF>(c);
+    min_step<0x140, 0xF>(c);
+    min_step<0x142, 0xA>(c);
+    min_step<0x143, 0xC>(c);
+    bv = m;
+    bi = c;
+}
+
 }  // namespace caf

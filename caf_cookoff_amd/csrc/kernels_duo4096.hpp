@@ -249,7 +249,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_duo_rows
         T bv = bv_lo;
         uint32_t bi = bv_lo > T(0) ? (uint32_t)(L.t + 256 * bi_lo) : 0u;
         if (bv_hi > bv) { bv = bv_hi; bi = (uint32_t)(L.t + 256 * bi_hi + F_N); }
-        wave_arg_reduce_dpp(bv, bi);
+        wave_arg_reduce_maxmin(bv, bi);
         T *sv = reinterpret_cast<T *>(scratch);
         uint32_t *si = reinterpret_cast<uint32_t *>(scratch + 32);
         if (L.lane == 63) { sv[L.wave] = bv; si[L.wave] = bi; }
