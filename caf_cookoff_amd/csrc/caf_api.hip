@@ -609,7 +609,7 @@ static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay,
     caf_ctx *c = p->ctx;
     const size_t rows = p->rows, total = batch * rows;
     int rc;
-    if ((rc = p->bhwork.ensure(batch * B_L * sizeof(cpx<T>)))) return rc;
+    if ((rc = p->bhwork.ensure((batch < 32768 ? batch : 32768) * B_L * sizeof(cpx<T>)))) return rc;
     if (!p->spec_override && (rc = p->spec.ensure(batch * B_L * sizeof(cpx<T>)))) return rc;
     BigArgs<T> a;
     a.phasor = (const cpx<T> *)p->d_phasor;
@@ -630,7 +630,15 @@ static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay,
     }
     KCHK();
     if (total == 0) return CAF_OK;
-    if ((rc = p->bwork.ensure(total * B_L * sizeof(cpx<T>)))) return rc;
+    // Rows are processed in chunks whose work rows (chunk x 64 Ki complex) fit the 256 MiB
+    // Infinity Cache, and every chunk reuses the SAME work buffer: the two intermediate passes
+    // hit on-die, and the intermediate data is overwritten in the cache instead of being
+    // written back to HBM once per row.
+    static const size_t chunk_env = getenv("CAF_BIG_CHUNK") ? (size_t)atol(getenv("CAF_BIG_CHUNK")) : 0;
+    size_t chunk = chunk_env ? chunk_env : (128u << 20) / (B_L * sizeof(cpx<T>));
+    if (chunk < 1) chunk = 1;
+    if (chunk > 32768) chunk = 32768;
+    if ((rc = p->bwork.ensure((total < chunk ? total : chunk) * B_L * sizeof(cpx<T>)))) return rc;
     if ((rc = p->bpart_val.ensure(total * 16 * sizeof(T)))) return rc;
     if ((rc = p->bpart_idx.ensure(total * 16 * sizeof(uint32_t)))) return rc;
     a.prepare = 0;
@@ -640,13 +648,6 @@ static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay,
     a.part_val = (T *)p->bpart_val.p;
     a.part_idx = (uint32_t *)p->bpart_idx.p;
     if ((rc = timing_mark(p))) return rc;
-    // Rows are processed in chunks whose work rows (chunk x 64 Ki complex) fit the 256 MiB
-    // Infinity Cache: the two intermediate passes then hit on-die instead of streaming the
-    // whole work buffer through HBM three times.
-    static const size_t chunk_env = getenv("CAF_BIG_CHUNK") ? (size_t)atol(getenv("CAF_BIG_CHUNK")) : 0;
-    size_t chunk = chunk_env ? chunk_env : (128u << 20) / (B_L * sizeof(cpx<T>));
-    if (chunk < 1) chunk = 1;
-    if (chunk > 32768) chunk = 32768;
     for (size_t w0 = 0; w0 < total; w0 += chunk) {
         const size_t nw = total - w0 < chunk ? total - w0 : chunk;
         a.wr0 = (unsigned)w0;

@@ -39,7 +39,7 @@ struct BigArgs {
     const cpx<T> *phasor;   // [rows+1][384]: A[r] = e^{j*ph*256*r} (r<128), B[c] = e^{j*ph*c} (c<256); last row = 1
     const cpx<T> *w256;     // e^{2*pi*i*j/256}, j < 256
     const cpx<T> *wL;       // e^{2*pi*i*j/65536}, j < 256
-    cpx<T> *work;           // [batch*rows][65536] work rows (prepare: [batch][65536])
+    cpx<T> *work;           // [rows of one launch][65536] work rows, indexed by blockIdx.y (reused by every chunk)
     cpx<T> *spec;           // H/L in k_big_rows register layout: [batch][256 k1][16 kb][16 s]
     T *surface;             // [batch*rows][65536] or nullptr
     T *part_val;            // [batch*rows][16] per column-tile argmax partials
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(B_THREADS) void k_big_cols_fwd(const BigArgs<T> A)
     }
     dif256(v, s, A.w256, [&](C(&x)[16]) { transpose_cols(x, lds, g, s); });
     // four-step twiddle W_L^(k1*c), k1 = s + 16*kb, and store Y[k1][c]
-    C *out = A.work + wr * B_L;
+    C *out = A.work + (size_t)blockIdx.y * B_L;  // work rows are chunk-local: the same 128 MiB is reused by every chunk
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
         const int k1 = s + 16 * kb;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(B_THREADS) void k_big_rows(const BigArgs<T> A)
     const int k1 = blockIdx.x * 16 + g;
     const size_t wr = (size_t)blockIdx.y + A.wr0;
     const size_t b = A.prepare ? wr : wr / A.rows;
-    C *row = A.work + wr * B_L + 256 * k1;
+    C *row = A.work + (size_t)blockIdx.y * B_L + 256 * k1;
     C v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = row[s + 16 * q];
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(B_THREADS) void k_big_cols_inv(const BigArgs<T> A)
     const int g = threadIdx.x & 15, s = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + g;
     const size_t wr = (size_t)blockIdx.y + A.wr0;
-    const C *in = A.work + wr * B_L;
+    const C *in = A.work + (size_t)blockIdx.y * B_L;
     C v[16];
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
