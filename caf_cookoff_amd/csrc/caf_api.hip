@@ -618,6 +618,9 @@ static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay,
     a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
     a.rows = (int)rows;
     a.surface = nullptr; a.part_val = nullptr; a.part_idx = nullptr;
+    // persistent launches: 16 tiles x gy_cap rows of workgroups ~ one resident set; each loops over its rows
+    static const size_t gy_env = getenv("CAF_BIG_GY") ? (size_t)atol(getenv("CAF_BIG_GY")) : 0;
+    const size_t gy_cap = gy_env ? gy_env : (size_t)c->cu_count * 3 / 16;  // 2.19-2.26 ms per 4096-row surface for 32...96
     // haystack spectrum once per surface
     a.prepare = 1;
     a.sig = (const cpx<T> *)d_hay;
@@ -625,8 +628,10 @@ static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay,
     for (size_t w0 = 0; w0 < batch; w0 += 32768) {
         const size_t nw = batch - w0 < 32768 ? batch - w0 : 32768;
         a.wr0 = (unsigned)w0;
-        k_big_cols_fwd<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
-        k_big_rows<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
+        a.nw = (unsigned)nw;
+        const unsigned gy = (unsigned)(nw < gy_cap ? nw : gy_cap);
+        k_big_cols_fwd<T><<<dim3(16, gy), B_THREADS, 0, c->stream>>>(a);
+        k_big_rows<T><<<dim3(16, gy), B_THREADS, 0, c->stream>>>(a);
     }
     KCHK();
     if (total == 0) return CAF_OK;
@@ -651,9 +656,11 @@ static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay,
     for (size_t w0 = 0; w0 < total; w0 += chunk) {
         const size_t nw = total - w0 < chunk ? total - w0 : chunk;
         a.wr0 = (unsigned)w0;
-        k_big_cols_fwd<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
-        k_big_rows<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
-        k_big_cols_inv<T><<<dim3(16, (unsigned)nw), B_THREADS, 0, c->stream>>>(a);
+        a.nw = (unsigned)nw;
+        const unsigned gy = (unsigned)(nw < gy_cap ? nw : gy_cap);
+        k_big_cols_fwd<T><<<dim3(16, gy), B_THREADS, 0, c->stream>>>(a);
+        k_big_rows<T><<<dim3(16, gy), B_THREADS, 0, c->stream>>>(a);
+        k_big_cols_inv<T><<<dim3(16, gy), B_THREADS, 0, c->stream>>>(a);
     }
     KCHK();
     k_big_rowpeak<T><<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(

@@ -46,7 +46,8 @@ struct BigArgs {
     uint32_t *part_idx;
     int rows;               // Doppler rows per surface in this plan
     int prepare;            // 1: haystack transform (phasor row = rows, one work row per surface)
-    unsigned wr0;           // first work row of this launch (gridDim.y is limited to 65535)
+    unsigned wr0;           // first work row of this launch
+    unsigned nw;            // work rows of this launch; a workgroup loops over rows y = blockIdx.y, +gridDim.y, ...
 };
 
 template <typename T>
@@ -87,6 +88,35 @@ __device__ __forceinline__ void dif256(cpx<T> (&v)[16], int s, const cpx<T> *w25
     transpose(v);
     dft16(v);
 }
+// Per-lane twiddles W_256^(s*k), k = 1..15: fetched ONCE per workgroup (a table gather per use
+// made all three kernels TA-bound: ~47-60 gather instructions per lane and tile).
+template <typename T>
+struct Tw256 {
+    cpx<T> w[16];
+    __device__ __forceinline__ Tw256(const cpx<T> *w256, int s)
+    {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) w[k] = w256[(s * k) & 255];
+    }
+};
+template <typename T, typename Ex>
+__device__ __forceinline__ void dif256(cpx<T> (&v)[16], const Tw256<T> &tw, Ex &&transpose)
+{
+    dft16(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw.w[k]);
+    transpose(v);
+    dft16(v);
+}
+template <typename T, typename Ex>
+__device__ __forceinline__ void dit256(cpx<T> (&v)[16], const Tw256<T> &tw, Ex &&transpose)
+{
+    dft16(v);
+    transpose(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw.w[k]);
+    dft16(v);
+}
 // mirrored DIT: k = s + 16*kb (kb = register) -> m = s + 16*q (q = register)
 template <typename T, typename Ex>
 __device__ __forceinline__ void dit256(cpx<T> (&v)[16], int s, const cpx<T> *w256, Ex &&transpose)
@@ -97,6 +127,10 @@ __device__ __forceinline__ void dit256(cpx<T> (&v)[16], int s, const cpx<T> *w25
     for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], w256[(s * k) & 255]);
     dft16(v);
 }
+
+// resident workgroups per CU the register allocator must leave room for (one wave of each per SIMD)
+template <typename T>
+constexpr int big_waves_per_simd() { return sizeof(T) == 4 ? 3 : 2; }
 
 template <typename T>
 constexpr size_t big_lds_bytes() { return 16 * B_P * sizeof(cpx<T>); }
@@ -127,14 +161,21 @@ __device__ __forceinline__ void transpose_rows(cpx<T> (&v)[16], cpx<T> *lds, int
 
 // ---- columns, forward: grid (16 column tiles, rows*batch) ------------------------------------
 template <typename T>
-__global__ __launch_bounds__(B_THREADS) void k_big_cols_fwd(const BigArgs<T> A)
+__global__ __launch_bounds__(B_THREADS, big_waves_per_simd<T>()) void k_big_cols_fwd(const BigArgs<T> A)
 {
     using C = cpx<T>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[big_lds_bytes<T>()];
     C *const lds = reinterpret_cast<C *>(smem);
     const int g = threadIdx.x & 15, s = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + g;
-    const size_t wr = (size_t)blockIdx.y + A.wr0;  // work row = b*rows + r  (prepare: b)
+    // Persistent over work rows (same column tile): the per-lane twiddles of the 256-point
+    // transform and of the four-step rotation W_L^(k1*c), k1 = s + 16*kb, live in registers.
+    const Tw256<T> tws(A.w256, s);
+    C twl[16];
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) twl[kb] = twiddle_L(A.w256, A.wL, (unsigned)((s + 16 * kb) * c));
+    for (unsigned y = blockIdx.y; y < A.nw; y += gridDim.y) {
+    const size_t wr = (size_t)y + A.wr0;  // work row = b*rows + r  (prepare: b)
     const size_t b = A.prepare ? wr : wr / A.rows;
     const int r = A.prepare ? A.rows : (int)(wr % A.rows);
     const C *sig = A.sig + b * B_N;
@@ -150,50 +191,54 @@ __global__ __launch_bounds__(B_THREADS) void k_big_cols_fwd(const BigArgs<T> A)
         else
             v[q] = C{T(0), T(0)};
     }
-    dif256(v, s, A.w256, [&](C(&x)[16]) { transpose_cols(x, lds, g, s); });
+    dif256(v, tws, [&](C(&x)[16]) { transpose_cols(x, lds, g, s); });
     // four-step twiddle W_L^(k1*c), k1 = s + 16*kb, and store Y[k1][c]
-    C *out = A.work + (size_t)blockIdx.y * B_L;  // work rows are chunk-local: the same 128 MiB is reused by every chunk
+    C *out = A.work + (size_t)y * B_L;  // work rows are chunk-local: the same 128 MiB is reused by every chunk
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
         const int k1 = s + 16 * kb;
-        out[256 * k1 + c] = cmul(v[kb], twiddle_L(A.w256, A.wL, (unsigned)(k1 * c)));
+        out[256 * k1 + c] = cmul(v[kb], twl[kb]);
+    }
     }
 }
 
 // ---- rows: forward, x H/L, inverse: grid (16 row tiles, rows*batch) -----------------------------
 template <typename T>
-__global__ __launch_bounds__(B_THREADS) void k_big_rows(const BigArgs<T> A)
+__global__ __launch_bounds__(B_THREADS, big_waves_per_simd<T>()) void k_big_rows(const BigArgs<T> A)
 {
     using C = cpx<T>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[big_lds_bytes<T>()];
     C *const lds = reinterpret_cast<C *>(smem);
     const int s = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int k1 = blockIdx.x * 16 + g;
-    const size_t wr = (size_t)blockIdx.y + A.wr0;
+    const Tw256<T> tws(A.w256, s);
+    for (unsigned y = blockIdx.y; y < A.nw; y += gridDim.y) {
+    const size_t wr = (size_t)y + A.wr0;
     const size_t b = A.prepare ? wr : wr / A.rows;
-    C *row = A.work + (size_t)blockIdx.y * B_L + 256 * k1;
+    C *row = A.work + (size_t)y * B_L + 256 * k1;
     C v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = row[s + 16 * q];
-    dif256(v, s, A.w256, [&](C(&x)[16]) { transpose_rows(x, lds, g, s); });
+    dif256(v, tws, [&](C(&x)[16]) { transpose_rows(x, lds, g, s); });
     // now v[kb] = Z[k1][k2 = s + 16*kb]; spectrum layout [k1][kb][s]
     C *spec = A.spec + b * B_L + 256 * k1;
     if (A.prepare) {
         const T inv = T(1.0 / 65536.0);
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) spec[16 * kb + s] = {v[kb].x * inv, -v[kb].y * inv};  // conj(.)/L
-        return;
+        continue;
     }
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) v[kb] = cmul(v[kb], spec[16 * kb + s]);
-    dit256(v, s, A.w256, [&](C(&x)[16]) { transpose_rows(x, lds, g, s); });
+    dit256(v, tws, [&](C(&x)[16]) { transpose_rows(x, lds, g, s); });
 #pragma unroll
     for (int q = 0; q < 16; ++q) row[s + 16 * q] = v[q];
+    }
 }
 
 // ---- columns, inverse + |.|^2 + argmax partials: grid (16 column tiles, rows*batch) ---------------
 template <typename T>
-__global__ __launch_bounds__(B_THREADS) void k_big_cols_inv(const BigArgs<T> A)
+__global__ __launch_bounds__(B_THREADS, big_waves_per_simd<T>() - 1) void k_big_cols_inv(const BigArgs<T> A)
 {
     using C = cpx<T>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[big_lds_bytes<T>()];
@@ -202,15 +247,20 @@ __global__ __launch_bounds__(B_THREADS) void k_big_cols_inv(const BigArgs<T> A)
     C *const lds = reinterpret_cast<C *>(smem);
     const int g = threadIdx.x & 15, s = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + g;
-    const size_t wr = (size_t)blockIdx.y + A.wr0;
-    const C *in = A.work + (size_t)blockIdx.y * B_L;
+    const Tw256<T> tws(A.w256, s);
+    C twl[16];
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) twl[kb] = twiddle_L(A.w256, A.wL, (unsigned)((s + 16 * kb) * c));
+    for (unsigned y = blockIdx.y; y < A.nw; y += gridDim.y) {
+    const size_t wr = (size_t)y + A.wr0;
+    const C *in = A.work + (size_t)y * B_L;
     C v[16];
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
         const int k1 = s + 16 * kb;
-        v[kb] = cmul(in[256 * k1 + c], twiddle_L(A.w256, A.wL, (unsigned)(k1 * c)));
+        v[kb] = cmul(in[256 * k1 + c], twl[kb]);
     }
-    dit256(v, s, A.w256, [&](C(&x)[16]) { transpose_cols(x, lds, g, s); });
+    dit256(v, tws, [&](C(&x)[16]) { transpose_cols(x, lds, g, s); });
     // v[q] = y[256*(s + 16*q) + c]
     T bv = T(0);
     uint32_t bi = 0;
@@ -232,6 +282,8 @@ __global__ __launch_bounds__(B_THREADS) void k_big_cols_inv(const BigArgs<T> A)
         for (int w = 1; w < 4; ++w) arg_merge(bv, bi, s_v[w], s_i[w]);
         A.part_val[wr * 16 + blockIdx.x] = bv;
         A.part_idx[wr * 16 + blockIdx.x] = bi;
+    }
+    __syncthreads();  // s_v / s_i are rewritten by the next row
     }
 }
 
