@@ -18,6 +18,7 @@
 #include "kernels_duo4096.hpp"
 #include "kernels_r8_4096.hpp"
 #include "kernels_big65536.hpp"
+#include "kernels_q65536.hpp"
 #include "kernels_generic.hpp"
 
 using namespace caf;
@@ -76,6 +77,7 @@ struct caf_ctx {
     void *th[2] = {nullptr, nullptr};
     void *bigw256[2] = {nullptr, nullptr};  // tiled65536 path tables
     void *bigwL[2] = {nullptr, nullptr};
+    void *qoutw[2] = {nullptr, nullptr};    // 16x4096 path: W_L^(k1 t)
     // generic FFT twiddles per (L, dtype)
     std::map<std::pair<size_t, int>, void *> tw_cache;
     // host-API staging + cached plan
@@ -92,6 +94,7 @@ struct caf_plan {
     size_t nfreq_total = 0, row_begin = 0, rows = 0;
     bool fused = false;
     bool big = false;           // n == 32768: four-step tiled path
+    bool bigq = false;          //   ... in its 16 x 4096 two-pass form (kernels_q65536.hpp)
     DevBuf bwork, bhwork, bpart_val, bpart_idx;
     double *d_freqs = nullptr;  // this shard's slice
     double *d_ph = nullptr;
@@ -209,6 +212,7 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
     for (int d = 0; d < 2; ++d) {
         if (c->bigw256[d]) (void)hipFree(c->bigw256[d]);
         if (c->bigwL[d]) (void)hipFree(c->bigwL[d]);
+        if (c->qoutw[d]) (void)hipFree(c->qoutw[d]);
     }
     for (auto &kv : c->tw_cache) (void)hipFree(kv.second);
     c->io_needle.release(); c->io_hay.release(); c->io_surface.release();
@@ -335,7 +339,19 @@ static int plan_build_tables(caf_plan *p)
     caf_ctx *c = p->ctx;
     const int dt = p->dtype;
     int rc;
-    if (p->big) {
+    if (p->big && p->bigq) {
+        if ((rc = build_fused_tables<T>(c, dt))) return rc;  // W_4096 for the 4096-point chains
+        if (!c->qoutw[dt]) {
+            HIPCHK(hipMalloc(&c->qoutw[dt], 4096 * sizeof(cpx<T>)));
+            k_q_tables<T><<<16, 256, 0, c->stream>>>((cpx<T> *)c->qoutw[dt]);
+            KCHK();
+        }
+        const size_t nr = p->rows + 1;  // +1: the w = 1 row of the haystack transform
+        HIPCHK(hipMalloc(&p->d_phasor, nr * 1024 * sizeof(cpx<T>)));
+        k_q_phasors<T><<<(unsigned)((nr * 1024 + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows,
+                                                                                 (cpx<T> *)p->d_phasor);
+        KCHK();
+    } else if (p->big) {
         if (!c->bigw256[dt]) {
             HIPCHK(hipMalloc(&c->bigw256[dt], 256 * sizeof(cpx<T>)));
             HIPCHK(hipMalloc(&c->bigwL[dt], 256 * sizeof(cpx<T>)));
@@ -390,6 +406,8 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     p->rows = row_end - row_begin;
     p->fused = (n == (size_t)F_N);
     p->big = (n == (size_t)B_N);
+    // CAF_BIG_PATH=1: the 16 x 4096 two-pass form (parity-green, 2.63 vs 2.19 ms per 4096-row surface)
+    p->bigq = p->big && getenv("CAF_BIG_PATH") && atoi(getenv("CAF_BIG_PATH")) == 1;
     p->variant = dtype == CAF_C64 ? 3 : 0;  // f32: two chains in flight; f64: sequential chains (kernels_duo4096.hpp)
     if (const char *ev = getenv("CAF_ROW_KERNEL")) p->variant = atoi(ev);
     int rc = CAF_OK;
@@ -440,6 +458,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
 {
     if (!p) return "";
     const bool f64 = p->dtype == CAF_C128;
+    if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";
     if (p->big) return f64 ? "caf::k_big_rows<double>" : "caf::k_big_rows<float>";
     if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
     if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0, 15>" : "caf::k_seq_rows<float, 0, 0, 15>";
@@ -601,6 +620,70 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     return CAF_OK;
 }
 
+// n = 32768 as 16 x 4096: two passes (kernels_q65536.hpp)
+template <typename T>
+static int surface_dev_q(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
+                         uint64_t *d_ridx, void *d_rval)
+{
+    caf_ctx *c = p->ctx;
+    const size_t rows = p->rows, total = batch * rows;
+    constexpr int RES = q_res<T>();
+    int rc;
+    if (!p->spec_override && (rc = p->spec.ensure(batch * B_L * sizeof(cpx<T>)))) return rc;
+    QArgs<T> a;
+    a.tw4096 = (const cpx<T> *)c->tw4096[p->dtype];
+    a.outw = (const cpx<T> *)c->qoutw[p->dtype];
+    a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
+    a.rows = (int)rows;
+    a.work = nullptr; a.surface = nullptr; a.part_val = nullptr; a.part_idx = nullptr;
+    size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
+    if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();
+    const size_t cap = (size_t)c->cu_count * per_cu;
+    const cpx<T> *phasor = (const cpx<T> *)p->d_phasor;
+    // haystack spectrum once per surface: the row kernel's front half with w = 1
+    a.prepare = 1;
+    a.sig = (const cpx<T> *)d_hay;
+    for (size_t w0 = 0; w0 < batch; w0 += 32768) {
+        const size_t nw = batch - w0 < 32768 ? batch - w0 : 32768;
+        a.wr0 = (unsigned)w0;
+        a.nw = (unsigned)nw;
+        const size_t tasks = nw * (16 / RES);
+        k_q_rows<T, RES><<<(unsigned)(tasks < cap ? tasks : cap), S_THREADS, 0, c->stream>>>(a, phasor);
+    }
+    KCHK();
+    if (total == 0) return CAF_OK;
+    // chunks of rows share one Infinity-Cache-resident work buffer (see surface_dev_big)
+    static const size_t chunk_env = getenv("CAF_BIG_CHUNK") ? (size_t)atol(getenv("CAF_BIG_CHUNK")) : 0;
+    size_t chunk = chunk_env ? chunk_env : (128u << 20) / (B_L * sizeof(cpx<T>));
+    if (chunk < 1) chunk = 1;
+    if (chunk > 32768) chunk = 32768;
+    if ((rc = p->bwork.ensure((total < chunk ? total : chunk) * B_L * sizeof(cpx<T>)))) return rc;
+    if ((rc = p->bpart_val.ensure(total * 8 * sizeof(T)))) return rc;
+    if ((rc = p->bpart_idx.ensure(total * 8 * sizeof(uint32_t)))) return rc;
+    a.prepare = 0;
+    a.sig = (const cpx<T> *)d_needle;
+    a.work = (cpx<T> *)p->bwork.p;
+    a.surface = (T *)d_surface;
+    a.part_val = (T *)p->bpart_val.p;
+    a.part_idx = (uint32_t *)p->bpart_idx.p;
+    if ((rc = timing_mark(p))) return rc;
+    const size_t cap_cols = (size_t)c->cu_count * 4;
+    for (size_t w0 = 0; w0 < total; w0 += chunk) {
+        const size_t nw = total - w0 < chunk ? total - w0 : chunk;
+        a.wr0 = (unsigned)w0;
+        a.nw = (unsigned)nw;
+        const size_t tasks = nw * (16 / RES), ctasks = nw * 8;
+        k_q_rows<T, RES><<<(unsigned)(tasks < cap ? tasks : cap), S_THREADS, 0, c->stream>>>(a, phasor);
+        k_q_cols<T><<<(unsigned)(ctasks < cap_cols ? ctasks : cap_cols), 256, 0, c->stream>>>(a);
+    }
+    KCHK();
+    k_q_rowpeak<T><<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(
+        (const T *)p->bpart_val.p, (const uint32_t *)p->bpart_idx.p, total, d_ridx, (T *)d_rval);
+    KCHK();
+    if ((rc = timing_mark(p))) return rc;
+    return CAF_OK;
+}
+
 // n = 32768: four-step tiled path (kernels_big65536.hpp)
 template <typename T>
 static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
@@ -732,10 +815,12 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
     int rc;
     if (p->dtype == CAF_C128)
         rc = p->fused ? surface_dev_fused<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+             : p->big && p->bigq ? surface_dev_q<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->big ? surface_dev_big<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
                       : surface_dev_generic<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     else
         rc = p->fused ? surface_dev_fused<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+             : p->big && p->bigq ? surface_dev_q<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->big ? surface_dev_big<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
                       : surface_dev_generic<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     if (rc) return rc;

@@ -35,6 +35,12 @@ __device__ __forceinline__ cpx<T> cmulc(cpx<T> a, cpx<T> b)
 }
 template <typename T>
 __device__ __forceinline__ cpx<T> cmul_conj(cpx<T> a, cpx<T> b) { return {a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x)}; }
+// acc + a*b
+template <typename T>
+__device__ __forceinline__ cpx<T> cfma(cpx<T> acc, cpx<T> a, cpx<T> b)
+{
+    return {acc.x + (a.x * b.x - a.y * b.y), acc.y + (a.x * b.y + a.y * b.x)};
+}
 template <typename T>
 __device__ __forceinline__ cpx<T> conj(cpx<T> a) { return {a.x, -a.y}; }
 // a + i b, a - i b
@@ -80,6 +86,15 @@ __device__ __forceinline__ cpx<float> sub_i(cpx<float> a, cpx<float> b)
 __device__ __forceinline__ cpx<float> cmul(cpx<float> a, cpx<float> b)
 {
     const caf_v2f av = pk(a), bv = pk(b), t = av.xx * bv;
+    caf_v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+    return unpk(r);
+}
+// acc + a*b: acc + a.x (b.x, b.y), then + a.y (-b.y, b.x)
+__device__ __forceinline__ cpx<float> cfma(cpx<float> acc, cpx<float> a, cpx<float> b)
+{
+    const caf_v2f av = pk(a), bv = pk(b), t = __builtin_elementwise_fma(av.xx, bv, pk(acc));
     caf_v2f r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
         : "=v"(r) : "v"(av), "v"(bv), "v"(t));

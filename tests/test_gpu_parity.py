@@ -543,6 +543,43 @@ def test_L65536_c128_tiled_path_and_negative_lag(eng, oracle):
     plan.close()
 
 
+def test_L65536_two_pass_variant(eng, oracle, monkeypatch):
+    """CAF_BIG_PATH=1: the 16 x 4096 two-pass form of the n = 32768 row (kernels_q65536.hpp) against
+    the numpy oracle, complex64 and complex128."""
+    from caf_cookoff_amd.synth import make_pair
+    monkeypatch.setenv("CAF_BIG_PATH", "1")
+    n = 32768
+    fr = np.array([11.5, 12.0, 12.5, -3.0])
+    for dtype, cdt, tol in (("c64", np.complex64, TOL32), ("c128", np.complex128, TOL64)):
+        s0, s1, lag, fo = make_pair(n=n, seed=91, lag=77, foffset=12.0, dtype=cdt)
+        plan = eng.plan(n, fr, FS, dtype=dtype)
+        assert plan.path == "tiled65536" and "k_q_rows" in plan.kernel_name
+        surf, ridx, rval, pk = _plan_arrays_n(plan, eng, s0, s1, dtype, n)
+        plan.close()
+        osurf, oidx, oval = oracle.np_caf_surface(s0.astype(np.complex128), s1.astype(np.complex128), fr, FS)
+        assert np.max(np.abs(surf - osurf)) <= tol * osurf.max()
+        assert (pk["freq"], int(pk["idx"])) == (12.0, lag)
+        if dtype == "c128":
+            assert np.array_equal(ridx.astype(np.uint64), oidx)
+
+
+def _plan_arrays_n(plan, eng, nd, hs, dtype, n):
+    import torch
+    import caf_cookoff_amd as caf
+    tdt = torch.float64 if dtype == "c128" else torch.float32
+    d_nd, d_hs = torch.from_numpy(nd[None]).cuda(), torch.from_numpy(hs[None]).cuda()
+    surf = torch.empty((1, plan.rows, 2 * n), dtype=tdt, device="cuda")
+    ridx = torch.empty((1, plan.rows), dtype=torch.int64, device="cuda")
+    rval = torch.empty((1, plan.rows), dtype=tdt, device="cuda")
+    peak = torch.empty((1, 4), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    plan.surface_dev(d_nd.data_ptr(), d_hs.data_ptr(), 1, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(),
+                     peak.data_ptr())
+    eng.synchronize()
+    pk = peak.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[0, 0]
+    return surf[0].cpu().numpy().astype(np.float64), ridx[0].cpu().numpy(), rval[0].cpu().numpy(), pk
+
+
 def test_generic_path_still_covers_other_big_sizes(eng, oracle):
     """n = 16384 (L = 32768) has no fused kernel: generic HBM-pass path."""
     from caf_cookoff_amd.synth import make_pair
