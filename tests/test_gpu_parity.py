@@ -732,3 +732,15 @@ def test_full_size_properties(eng, oracle):
     s_b, i_b, v_b, p_b = eng.surface_arrays(nd, hs_b, fr2, FS)
     assert np.max(np.abs(np.roll(s_a, d, axis=1) - s_b)) <= 1e-12 * s_a.max()
     assert (p_b.freq, p_b.idx) == (p_a.freq, p_a.idx + d) and p_a.idx == 50
+
+
+def test_short_soak():
+    """Three seconds of tools/soak.py: random (dtype, batch, row shard) cases, batched results must
+    equal one-surface results bit for bit (static and ticket row assignment, both product kernels)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "soak.py"), "3"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout + r.stderr
