@@ -1,44 +1,103 @@
 #!/usr/bin/env python3
 """bench.py -- CAF surfaces/sec on MI355X (BASELINE.json metric), one rank per GPU.
 
-  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torchrun)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input: `--batch`
-(default 128) distinct (needle, haystack) pairs per GPU, each a 400 x 8192 complex128 filterbank
-CAF (BASELINE configs[1]: n = 4096 samples, 400 shifts -100..99.5 Hz, fs = 48 kHz),
-inputs resident in HBM, surfaces + per-row peaks + global peak left in HBM.
+N > 1 without a torchrun environment: this process (before it imports torch or touches HIP)
+starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>`
+as a CHILD process, relays rank 0's JSON line and exits with the child's status.  Launched by
+torchrun directly (RANK/WORLD_SIZE set) it runs as one rank.
 
-N > 1 (weak scaling): the step covers N*batch surfaces; rank r
-computes the contiguous Doppler-row shard [r*F/N, (r+1)*F/N) of EVERY surface, then
-one RCCL all-reduce(max) over the N*batch peak values and one all-reduce(min) over
-(global_row<<32|idx) keys of the ranks that hold the max give every surface's global
-(tau, f) with the reference's first-row-wins tie-break (--peak-reduce allgather does the
-same with a single all_gather).  Per-GPU work is constant.
+A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 128)
+distinct (needle, haystack) pairs per GPU, each a 400 x 8192 complex128 filterbank CAF
+(BASELINE configs[1]: n = 4096 samples, 400 shifts -100..99.5 Hz, fs = 48 kHz), inputs resident
+in HBM, surfaces + per-row peaks + global peak left in HBM.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
-(dominant kernel, HBM bound, algorithmic bytes / HIP-event kernel time) and
-`cpu_baseline` (the C restatement of caf_rust timed on this box's host cores).
+N > 1 (weak scaling): the step covers N*batch surfaces; rank r computes the
+contiguous Doppler-row shard [r*F/N, (r+1)*F/N) of EVERY surface, then one RCCL all-reduce(max)
+over the N*batch peak values and one all-reduce(min) over (global_row<<32|idx) keys of the ranks
+that hold the max give every surface's global (tau, f) with the reference's first-row-wins
+tie-break (--peak-reduce allgather does the same with a single all_gather).  Per-GPU work is
+constant.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with
+  `roofline`     dominant kernel, HBM bound, algorithmic bytes / HIP-event kernel time; for the
+                 complex128 headline also `secondary` = the FP64-VALU issue ceiling of the
+                 shipped instruction stream, measured live with the math-only ablation of the
+                 measurement library (no LDS traffic, no loads, no stores);
+  `cpu_baseline` the C restatement of caf_rust timed on this box's host cores (model and
+                 core counts stated);
+  `extra`        (N = 1) the other BASELINE configs measured in the same process after the
+                 headline: configs[2] complex64, configs[3] 4096 x 65536 complex64 (whole surface
+                 and the 512-row shard one of 8 GPUs gets), configs[4] streaming.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
-
-import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 FS = 48000
 N_SAMP = 4096
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="surfaces per GPU per step (128 x 400 rows = 100 rows "
+                    "per resident workgroup on 256 CUs x 2; throughput saturates from ~128: profiles/r01_v4)")
+    ap.add_argument("--dtype", choices=["c128", "c64"], default="c128")
+    ap.add_argument("--nfreq", type=int, default=400)
+    ap.add_argument("--n", type=int, default=N_SAMP, help="samples per input (4096 = configs[1]/[2]; "
+                    "32768 with --nfreq 4096 --dtype c64 --batch 1 = configs[3])")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[2]/[3]/[4] measurements (N = 1)")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the live FP64-VALU ceiling measurement")
+    ap.add_argument("--peak-reduce", choices=["allreduce", "allgather"], default="allreduce",
+                    help="N>1: RCCL all-reduce(max) + all-reduce(min key) (BASELINE north_star), or one all_gather")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no GPU work: launch + rendezvous + peak reduction + JSON relay on fabricated shard peaks "
+                         "(gloo); what the CPU test suite runs")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------- launcher --
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 outside torchrun: run the N ranks as a child process tree.  Nothing in THIS
+    process has imported torch or touched HIP (a process that initialised the GPU must never be
+    replaced or fork GPU users on this pool)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve()),
+           *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode  # stdout is inherited: rank 0's JSON line is ours
+
+
+# ------------------------------------------------------------------------------ helpers --
 def algorithmic_bytes(n_surfaces: int, rows_local: int, n: int, dtype: str) -> int:
     """inputs once + outputs once.  Per surface and row shard:
     needle+haystack 2*n*csize, surface rows*2n*rsize, row peaks rows*(8+rsize);
@@ -48,11 +107,22 @@ def algorithmic_bytes(n_surfaces: int, rows_local: int, n: int, dtype: str) -> i
     return n_surfaces * per_surface + rows_local * 8
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: ties a profiles/*/traffic.json to the code it measured."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "caf_cookoff_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def profiled_traffic(kernel_name: str, nsurf: int, dtype: str):
-    """HBM bytes per launch of the dominant kernel from the PMC passes committed under
-    profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command, corrected as
-    MI355X_MICROARCH.md prescribes; tools/profile_pack.py).  None if no matching profile."""
-    best = None
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes; tools/profile_pack.py).  Collected offline, so it is only
+    reported when the profile's kernel-source hash equals the running code's; otherwise null."""
+    here = kernel_source_hash()
+    best, stale = None, None
     for f in sorted((ROOT / "profiles").glob("*/traffic.json")):
         try:
             t = json.loads(f.read_text())
@@ -60,15 +130,36 @@ def profiled_traffic(kernel_name: str, nsurf: int, dtype: str):
             continue
         if t.get("kernel") and t["kernel"] in kernel_name and t.get("surfaces_per_launch") == nsurf and \
                 t.get("dtype") == ("f64" if dtype == "c128" else "f32"):
-            best = (t["traffic_bytes_per_launch"], str(f.relative_to(ROOT)))
-    return best
+            if t.get("source_hash") == here:
+                best = (t["traffic_bytes_per_launch"], str(f.relative_to(ROOT)))
+            else:
+                stale = str(f.relative_to(ROOT))
+    return best, stale
 
 
-def cpu_baseline(seconds: float, threads: int):
+def host_cpu_info():
+    model = "unknown"
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"model": model, "nproc_online": os.cpu_count() or 1, "nproc_usable": usable}
+
+
+def cpu_baseline(seconds: float, max_threads: int):
     """C restatement of caf_rust (oracle/caf_oracle.c; 3 FFTs per row like
     xcor_rustfft.rs:58-61, one task per row like CafRustFFTThreadpool) on the
     reference's own chirp_0 bench input, timed on this host's cores."""
     from oracle import caf_oracle as O
+    info = host_cpu_info()
+    threads = max(1, min(info["nproc_usable"], max_threads))  # a 1-GPU box's CPU share is 16 cores
     co = O.COracle()
     nd, hs = O.load_pair(O.default_data_dir(), "chirp_0_raw.c64", O.KATS[0][1])
     fr = O.bench_shifts()
@@ -91,51 +182,218 @@ def cpu_baseline(seconds: float, threads: int):
         "value": 1.0 / mt, "unit": "surfaces/s", "cores": threads, "kind": "port",
         "sample": f"{reps} x (400x8192 c128, chirp_0 pair, 3 FFTs/row, {threads} threads) in {el:.1f}s",
         "ms_per_surface": mt * 1e3, "single_thread_ms_per_surface": st * 1e3,
+        "host_cpu": info["model"], "host_nproc": info["nproc_online"], "host_nproc_usable": info["nproc_usable"],
         "published_reference_ms": {"rust RustFFT 1 thread (R9-3900X)": 177, "rust RustFFT threadpool (R9-3900X)": 28},
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="surfaces per GPU per step (128 x 400 rows = 100 rows "
-                    "per resident workgroup on 256 CUs x 2; throughput saturates from ~128: profiles/r01_v4)")
-    ap.add_argument("--dtype", choices=["c128", "c64"], default="c128")
-    ap.add_argument("--nfreq", type=int, default=400)
-    ap.add_argument("--n", type=int, default=N_SAMP, help="samples per input (4096 = configs[1]/[2]; "
-                    "32768 with --nfreq 4096 --dtype c64 --batch 1 = configs[3])")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--peak-reduce", choices=["allreduce", "allgather"], default="allreduce",
-                    help="N>1: RCCL all-reduce(max) + all-reduce(min key) (BASELINE north_star), or one all_gather")
-    args = ap.parse_args()
+class Case:
+    """One (n, freq list, dtype, row shard, batch) workload with its device buffers."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, eng, torch, dev, n, freqs, dtype, batch, lo, hi, seed0=1000, want_surface=True):
+        import numpy as np
+        from caf_cookoff_amd.synth import make_batch
+        self.torch, self.n, self.dtype, self.batch, self.freqs = torch, n, dtype, batch, freqs
+        self.rows = hi - lo
+        cdt = np.complex128 if dtype == "c128" else np.complex64
+        rdt = torch.float64 if dtype == "c128" else torch.float32
+        nd_h, hs_h, self.lags, self.fos = make_batch(batch, n, FS, seed0=seed0, dtype=cdt)
+        self.nd = torch.from_numpy(nd_h).to(dev)
+        self.hs = torch.from_numpy(hs_h).to(dev)
+        self.plan = eng.plan(n, freqs, FS, dtype=dtype, row_begin=lo, row_end=hi)
+        self.surf = torch.empty((batch, self.rows, 2 * n), dtype=rdt, device=dev) if want_surface else None
+        self.ridx = torch.empty((batch, self.rows), dtype=torch.int64, device=dev)
+        self.rval = torch.empty((batch, self.rows), dtype=rdt, device=dev)
+        self.peak = torch.empty((batch, 4), dtype=torch.float64, device=dev)  # caf_peak records (32 B)
+        self.peak_i = self.peak.view(torch.int64)
 
+    def launch(self, plan=None):
+        (plan or self.plan).surface_dev(self.nd.data_ptr(), self.hs.data_ptr(), self.batch,
+                                        self.surf.data_ptr() if self.surf is not None else None,
+                                        self.ridx.data_ptr(), self.rval.data_ptr(), self.peak.data_ptr())
+
+    def host_peaks(self):
+        import numpy as np
+        pk = self.peak.cpu().numpy().view([("val", "<f8"), ("freq", "<f8"), ("idx", "<u8"), ("row", "<i8")])[:, 0]
+        return pk["idx"].astype(np.int64), pk["freq"], pk["row"]
+
+    def check(self, g_idx, g_freq, tol_hz):
+        import numpy as np
+        for b in range(self.batch):
+            want_f = self.freqs[np.argmin(np.abs(self.freqs - self.fos[b]))]
+            assert int(g_idx[b]) == self.lags[b], f"surface {b}: tau {g_idx[b]} != {self.lags[b]}"
+            assert abs(float(g_freq[b]) - want_f) <= tol_hz + 1e-9, f"surface {b}: f {g_freq[b]} vs {self.fos[b]}"
+
+    def timed(self, steps, warmup):
+        """-> (seconds per step, kernel ms per launch, launches)."""
+        torch = self.torch
+        for _ in range(warmup):
+            self.launch()
+        torch.cuda.synchronize()
+        self.plan.timing_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.launch()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ms, launches = self.plan.timing_end()
+        return el / steps, ms / max(1, launches), launches
+
+    def close(self):
+        self.plan.close()
+        self.surf = self.ridx = self.rval = self.peak = self.peak_i = self.nd = self.hs = None
+
+
+def roofline_entry(abytes, kern_ms):
+    achieved = abytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+
+
+def valu_ceiling(torch, dev, case, steps=10):
+    """FP64-VALU issue ceiling of the shipped row kernel, measured live: the measurement library's
+    math-only ablation (CAF_STORE_MODE=33: the product kernel's instruction stream with LDS traffic,
+    global loads and stores removed; wrong results, timing only) on the same batch and buffers."""
+    import caf_cookoff_amd as caf
+    if not caf.MEASURE_LIB_PATH.exists():
+        return None
+    old = os.environ.get("CAF_STORE_MODE")
+    os.environ["CAF_STORE_MODE"] = "33"
+    try:
+        meng = caf.Engine(dev.index or 0, lib=caf.MEASURE_LIB_PATH)
+        meng.set_stream(torch.cuda.current_stream().cuda_stream)
+        plan = meng.plan(case.n, case.freqs, FS, dtype=case.dtype, row_begin=case.plan.row_begin,
+                         row_end=case.plan.row_begin + case.rows)
+        for _ in range(3):
+            case.launch(plan)
+        torch.cuda.synchronize()
+        plan.timing_begin()
+        for _ in range(steps):
+            case.launch(plan)
+        ms, launches = plan.timing_end()
+        plan.close()
+        meng.close()
+        return ms / max(1, launches)
+    finally:
+        if old is None:
+            os.environ.pop("CAF_STORE_MODE", None)
+        else:
+            os.environ["CAF_STORE_MODE"] = old
+
+
+def stream_case(eng, torch, freqs, total=1000, nslots=2, batch=1, group=1):
+    """BASELINE configs[4]: `total` back-to-back single-surface steps from pinned host memory,
+    double-buffered H2D, hipGraph replay per slot, surfaces left on the device, (tau, f) + row
+    peaks copied back.  Sustained surfaces/s over the whole run including H2D and D2H."""
     import caf_cookoff_amd as caf
     from caf_cookoff_amd.synth import make_batch
+    plan = eng.plan(N_SAMP, freqs, FS)
+    pool_n = 64
+    nd, hs, lags, _ = make_batch(pool_n, N_SAMP, FS, seed0=5000)
+    st = caf.Stream(plan, batch=batch, nslots=nslots, want_surface=True)
+    bufs = [st.buffers(s) for s in range(nslots)]
+    steps = max(nslots + 1, total // batch)
+    best = None
+    ok = 0
+    for rep in range(2):  # first pass warms the graphs up
+        ok = 0
+        t0 = time.perf_counter()
+        inflight = []
+        for step in range(steps):
+            slot = step % nslots
+            if len(inflight) == nslots:
+                s0, step0 = inflight.pop(0)
+                peaks, _, _ = st.wait(s0, want_rows=False)
+                ok += int(peaks[0]["idx"]) == lags[(step0 * batch) % pool_n]
+            a, b = bufs[slot]
+            for j in range(batch):
+                k = (step * batch + j) % pool_n
+                a[j], b[j] = nd[k], hs[k]
+            st.submit(slot)
+            inflight.append((slot, step))
+        for s0, step0 in inflight:
+            peaks, _, _ = st.wait(s0, want_rows=False)
+            ok += int(peaks[0]["idx"]) == lags[(step0 * batch) % pool_n]
+        best = time.perf_counter() - t0
+    st.close()
+    plan.close()
+    nsurf = steps * batch
+    abytes = algorithmic_bytes(1, 400, N_SAMP, "c128")
+    return {"workload": f"{nsurf} back-to-back 400x8192 complex128 surfaces from pinned host memory, {nslots} slots x "
+                        f"{batch} surface(s) per hipGraph replay, H2D of inputs and D2H of peaks included (BASELINE configs[4])",
+            "value": nsurf / best, "unit": "surfaces/s", "us_per_surface": best / nsurf * 1e6,
+            "tau_correct": f"{ok}/{steps}", "algorithmic_bytes_per_surface": abytes,
+            "frac": abytes * nsurf / best / 1e9 / HBM_PEAK_GBS}
 
+
+# -------------------------------------------------------------------------- plumbing only --
+def plumbing_only(args):
+    """The N>1 control path without a GPU: rendezvous over gloo, reduce fabricated shard peaks with
+    the product's reduce_global_peak, rank 0 prints the JSON line."""
+    import torch
+    import torch.distributed as dist
+    from caf_cookoff_amd.dist import reduce_global_peak
+    from caf_cookoff_amd.shifts import shard_range
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    F, nsurf = args.nfreq, 4 * world
+    lo, hi = shard_range(F, rank, world)
+    # surface b peaks on global row (37*b) % F; ranks that do not own the row report a lower local peak
+    want_row = torch.tensor([(37 * b) % F for b in range(nsurf)], dtype=torch.int64)
+    mine = (want_row >= lo) & (want_row < hi)
+    val = torch.where(mine, torch.full((nsurf,), 9.0, dtype=torch.float64), torch.full((nsurf,), 1.0 + rank, dtype=torch.float64))
+    row = torch.where(mine, want_row, torch.full((nsurf,), lo, dtype=torch.int64))
+    idx = torch.where(mine, torch.arange(nsurf) + 100, torch.zeros(nsurf, dtype=torch.int64))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gmax, grow, gidx = reduce_global_peak(val, row, idx, method=args.peak_reduce)
+    el = time.perf_counter() - t0
+    assert torch.equal(grow, want_row) and torch.equal(gidx, torch.arange(nsurf) + 100) and bool((gmax == 9.0).all())
+    n_seen = dist.get_world_size() if world > 1 else 1
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "n_gpus": n_seen, "steps": args.steps, "value": None,
+                          "ms_per_step": el / max(1, args.steps) * 1e3, "peak_reduce": args.peak_reduce}), flush=True)
+    return 0
+
+
+# --------------------------------------------------------------------------------- main --
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(self_launch(args))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.plumbing_only:
+        sys.exit(plumbing_only(args))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.dist import reduce_global_peak
+
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists)")
     # Rehearsal mode for a one-GPU box (never used by the driver): every rank shares cuda:0 and
     # the peak reduction runs over gloo on CPU copies; everything else is the N>1 code path.
     rehearse = os.environ.get("CAF_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    ndev = torch.cuda.device_count()
     if rehearse:
         local_rank = 0
+    elif local_rank >= ndev:
+        sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {ndev} device(s) are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -144,6 +402,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        # every rank must see at least N devices (one process per GPU on ONE node)
+        t = torch.tensor([ndev], dtype=torch.int64, device="cpu" if rehearse else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if not rehearse and int(t.item()) < world:
+            sys.exit(f"bench.py: a rank sees only {int(t.item())} device(s) for a {world}-GPU run")
+    n_gpus_seen = dist.get_world_size() if world > 1 else 1
 
     eng = caf.Engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -155,30 +419,19 @@ def main():
     lo, hi = caf.shard_range(F, rank, world)
     rows = hi - lo
     nsurf = args.batch * world  # surfaces per step (whole job)
-    cdt = np.complex128 if args.dtype == "c128" else np.complex64
-    rdt = torch.float64 if args.dtype == "c128" else torch.float32
-    nd_h, hs_h, lags, fos = make_batch(nsurf, n_samp, FS, seed0=1000, dtype=cdt)
-    nd = torch.from_numpy(nd_h).to(dev)
-    hs = torch.from_numpy(hs_h).to(dev)
-    plan = eng.plan(n_samp, freqs, FS, dtype=args.dtype, row_begin=lo, row_end=hi)
-    surf = torch.empty((nsurf, rows, 2 * n_samp), dtype=rdt, device=dev)
-    ridx = torch.empty((nsurf, rows), dtype=torch.int64, device=dev)
-    rval = torch.empty((nsurf, rows), dtype=rdt, device=dev)
-    peak = torch.empty((nsurf, 4), dtype=torch.float64, device=dev)  # caf_peak records (32 B)
-    peak_i = peak.view(torch.int64)
-    from caf_cookoff_amd.dist import reduce_global_peak
+    case = Case(eng, torch, dev, n_samp, freqs, args.dtype, nsurf, lo, hi)
+    plan = case.plan
 
     def step():
-        plan.surface_dev(nd.data_ptr(), hs.data_ptr(), nsurf, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(),
-                         peak.data_ptr())
+        case.launch()
         if world == 1:
             return None
         # find_peak across the row shards: RCCL all-reduce(max) + all-reduce(min) on 8 B per surface
         if rehearse:
-            pk_c = peak.cpu()
+            pk_c = case.peak.cpu()
             pk_ci = pk_c.view(torch.int64)
             return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2], method=args.peak_reduce)
-        return reduce_global_peak(peak[:, 0], peak_i[:, 3], peak_i[:, 2], method=args.peak_reduce)
+        return reduce_global_peak(case.peak[:, 0], case.peak_i[:, 3], case.peak_i[:, 2], method=args.peak_reduce)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -192,25 +445,23 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    out = None
     for _ in range(args.warmup):
         out = step()
     sync_all()
 
     # ---- correctness gate on the warmed-up result (cheap; outside the timed region) ----
     if not args.no_check:
+        if args.warmup == 0:
+            out = step()
         torch.cuda.synchronize()
         if world == 1:
-            pk = peak.cpu().numpy().view([("val", "<f8"), ("freq", "<f8"), ("idx", "<u8"), ("row", "<i8")])[:, 0]
-            g_idx = pk["idx"].astype(np.int64)
-            g_freq = pk["freq"]
+            g_idx, g_freq, _ = case.host_peaks()
         else:
             gmax, grow, gidx = out
             g_idx = gidx.cpu().numpy()
             g_freq = freqs[grow.cpu().numpy()]
-        for b in range(nsurf):
-            want_f = freqs[np.argmin(np.abs(freqs - fos[b]))]
-            assert int(g_idx[b]) == lags[b], f"surface {b}: tau {g_idx[b]} != {lags[b]}"
-            assert abs(float(g_freq[b]) - want_f) <= 0.5 + 1e-9, f"surface {b}: f {g_freq[b]} vs {fos[b]}"
+        case.check(g_idx, g_freq, 0.5 if F == 400 else abs(freqs[1] - freqs[0]))
 
     # ---- timed region: exactly K steps between barriers --------------------------------
     K = args.steps
@@ -227,48 +478,97 @@ def main():
     kern_ms_total, launches = plan.timing_end()
     el = allreduce_max_time(el)
 
+    res = None
     if rank == 0:
         value = nsurf * K / el
         kern_ms = kern_ms_total / max(1, launches)
         abytes = algorithmic_bytes(nsurf, rows, n_samp, args.dtype)
-        achieved = abytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = profiled_traffic(plan.kernel_name, nsurf, args.dtype) if world == 1 else None
+        roof = roofline_entry(abytes, kern_ms)
+        traffic, stale = profiled_traffic(plan.kernel_name, nsurf, args.dtype) if world == 1 else (None, None)
+        roof.update({"traffic": traffic[0] if traffic else None,
+                     "traffic_source": (traffic[1] + " (rocprofv3 PMC passes of this command, collected offline; "
+                                        "kernel-source hash matches)") if traffic else
+                                       (f"none: {stale} was measured on other kernel sources" if stale else None),
+                     "kernel": plan.kernel_name, "kernel_ms": kern_ms, "launches_timed": launches,
+                     "algorithmic_bytes_per_launch": abytes,
+                     "frac_of_achievable_6.29TBs": roof["achieved"] / HBM_ACHIEVABLE_GBS,
+                     "whole_step_frac": (abytes * K / el / 1e9) / HBM_PEAK_GBS})
+        cfg_idx = 3 if n_samp == 32768 else 1 if args.dtype == "c128" else 2
         res = {
             "metric": "CAF surfaces/sec (400 freqs x 8192 samp, c128)"
                       if (F == 400 and args.dtype == "c128" and n_samp == N_SAMP)
                       else f"CAF surfaces/sec ({F} freqs x {2 * n_samp} samp, {args.dtype})",
-            "value": value, "unit": "surfaces/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "value": value, "unit": "surfaces/s", "n_gpus": n_gpus_seen, "steps": K, "warmup": args.warmup,
             "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.dtype == "c128" else "f32", "data": "synthetic",
             "config": {"workload": f"{F}x{2 * n_samp} {'complex128' if args.dtype == 'c128' else 'complex64'} "
-                                   f"filterbank CAF (BASELINE configs["
-                                   f"{3 if n_samp == 32768 else 1 if args.dtype == 'c128' else 2}]), n={n_samp}, fs=48000",
+                                   f"filterbank CAF (BASELINE configs[{cfg_idx}]), n={n_samp}, fs=48000",
                        "surfaces_per_step": nsurf, "batch_per_gpu": args.batch,
                        "rows_per_gpu": rows, "parallelism": f"doppler-row-shard x{world}" if world > 1 else "single",
-                       "kernel_path": plan.path, "device": devname, "cus": cu},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
-                         "traffic_source": traffic[1] if traffic else None,
-                         "kernel": plan.kernel_name,
-                         "kernel_ms": kern_ms, "launches_timed": launches,
-                         "algorithmic_bytes_per_launch": abytes,
-                         "frac_of_achievable_6.29TBs": achieved / HBM_ACHIEVABLE_GBS,
-                         "whole_step_frac": (abytes * K / el / 1e9) / HBM_PEAK_GBS},
+                       "kernel_path": plan.path, "device": devname, "cus": cu,
+                       "devices_visible_per_rank": ndev, "kernel_source_hash": kernel_source_hash()},
+            "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
-            threads = os.cpu_count() or 1
+    # ---- live FP64-VALU ceiling of the shipped instruction stream (headline shape only) ----
+    if rank == 0 and world == 1 and args.dtype == "c128" and n_samp == N_SAMP and not args.no_ceiling:
+        try:
+            ceil_ms = valu_ceiling(torch, dev, case)
+        except Exception as e:  # measurement aid only: never fail the bench line for it
+            ceil_ms = None
+            print(f"bench.py: VALU ceiling not measured: {e}", file=sys.stderr)
+        if ceil_ms:
+            res["roofline"]["secondary"] = {
+                "bound": "valu_f64", "ceiling_ms": ceil_ms, "frac_of_ceiling": ceil_ms / res["roofline"]["kernel_ms"],
+                "ceiling_frac_of_hbm": res["roofline"]["algorithmic_bytes_per_launch"] / (ceil_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "how": "math-only ablation of the product kernel (libcaf_hip_measure.so, CAF_STORE_MODE=33), same batch"}
+    case.close()
+
+    # ---- the other BASELINE configs, same process, after the headline (N = 1 only) ------
+    if rank == 0 and world == 1 and not args.no_extra and F == 400 and n_samp == N_SAMP and args.dtype == "c128":
+        extra = {}
+        torch.cuda.empty_cache()
+
+        def plan_case(name, n, freqs_x, dtype, batch, lo_x, hi_x, steps, warmup, cfg):
+            c = Case(eng, torch, dev, n, freqs_x, dtype, batch, lo_x, hi_x, seed0=3000)
             try:
-                threads = len(os.sched_getaffinity(0))
-            except AttributeError:
-                pass
-            threads = min(threads, args.cpu_threads)  # a 1-GPU box's CPU share is 16 cores
-            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, threads)
+                sec, kms, nl = c.timed(steps, warmup)
+                if not args.no_check:
+                    g_idx, g_freq, _ = c.host_peaks()
+                    if lo_x == 0 and hi_x == len(freqs_x):
+                        c.check(g_idx, g_freq, abs(freqs_x[1] - freqs_x[0]))
+                ab = algorithmic_bytes(batch, hi_x - lo_x, n, dtype)
+                e = roofline_entry(ab, kms)
+                extra[name] = {"workload": cfg, "value": batch / sec, "unit": "surfaces/s" if hi_x - lo_x == len(freqs_x)
+                               else "row-shards/s", "ms_per_step": sec * 1e3, "steps": steps,
+                               "kernel": c.plan.kernel_name, "kernel_path": c.plan.path, "kernel_ms": kms,
+                               "algorithmic_bytes": ab, "achieved_GBs": e["achieved"], "frac": e["frac"]}
+            finally:
+                c.close()
+                torch.cuda.empty_cache()
+
+        try:
+            plan_case("configs2_c64", N_SAMP, freqs, "c64", args.batch, 0, 400, max(5, min(K, 30)), 3,
+                      "400x8192 complex64 filterbank CAF (BASELINE configs[2]), batch %d" % args.batch)
+            f3 = np.arange(4096) * 0.05 - 102.4   # 0.05 Hz grid
+            plan_case("configs3_c64_full", 32768, f3, "c64", 1, 0, 4096, 5, 2,
+                      "4096x65536 complex64 filterbank CAF, all rows on ONE GPU (BASELINE configs[3] shape)")
+            lo3, hi3 = caf.shard_range(4096, 3, 8)
+            plan_case("configs3_c64_shard", 32768, f3, "c64", 1, lo3, hi3, 10, 2,
+                      "rows [1536,2048) of 4096x65536 complex64: the shard rank 3 of 8 GPUs computes (BASELINE configs[3])")
+            extra["configs4_stream"] = stream_case(eng, torch, freqs, total=1000, nslots=2, batch=1)
+        except Exception as e:
+            extra["error"] = f"{type(e).__name__}: {e}"
+        res["extra"] = extra
+
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.cpu_threads)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
-    plan.close()
+        print(json.dumps(res), flush=True)
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -12,6 +12,8 @@ from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libcaf_hip.so"
+# -DCAF_MEASURE build: rejected kernel variants + ablation switches (tools/ and the variant tests only)
+MEASURE_LIB_PATH = _HERE / "libcaf_hip_measure.so"
 
 CAF_OK = 0
 CAF_ERR_BAD_ARG = 1
@@ -82,7 +84,7 @@ SYMBOLS = [
     ("caf_stream_surface", _vp, [_vp, _int]),
 ]
 
-_lib = None
+_libs: dict = {}
 
 
 def _prefer_torch_hip_runtime() -> None:
@@ -111,12 +113,12 @@ def _prefer_torch_hip_runtime() -> None:
                 return
 
 
-def load() -> ctypes.CDLL:
-    """Load libcaf_hip.so and bind every declared symbol; raise if absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = Path(os.environ.get("CAF_HIP_LIB", LIB_PATH))
+def load(path=None) -> ctypes.CDLL:
+    """Load libcaf_hip.so (or the library at `path`, e.g. MEASURE_LIB_PATH) and bind every
+    declared symbol; raise if absent."""
+    path = Path(path if path is not None else os.environ.get("CAF_HIP_LIB", LIB_PATH)).resolve()
+    if str(path) in _libs:
+        return _libs[str(path)]
     if not path.exists():
         raise ImportError(
             f"{path} not found: build the HIP extension first "
@@ -128,11 +130,11 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[str(path)] = lib
     return lib
 
 
-def check(rc: int) -> None:
+def check(rc: int, lib=None) -> None:
     if rc != CAF_OK:
-        msg = load().caf_last_error_string()
+        msg = (lib or load()).caf_last_error_string()
         raise CafError(rc, msg.decode() if msg else "")

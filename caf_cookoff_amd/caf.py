@@ -10,6 +10,7 @@ arithmetic runs in the HIP kernels behind ``libcaf_hip.so``.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -49,18 +50,28 @@ class CafSurfaceRow:
 
 
 class Engine:
-    """One ``caf_ctx``: a GPU, a stream, cached plans.  Not thread-safe."""
+    """One ``caf_ctx``: a GPU, a stream, cached plans.  Not thread-safe.
+    ``lib`` selects another build of the C-ABI library (``MEASURE_LIB_PATH`` for tools/)."""
 
-    def __init__(self, device: int = 0):
-        self.lib = _lib.load()
+    def __init__(self, device: int = 0, lib=None):
+        self._h = None
+        self._plans = weakref.WeakSet()
+        self.lib = _lib.load(lib)
         h = ctypes.c_void_p()
-        check(self.lib.caf_ctx_create(int(device), ctypes.byref(h)))
+        self._check(self.lib.caf_ctx_create(int(device), ctypes.byref(h)))
         self._h = h
         self.device = int(device)
 
+    def _check(self, rc: int):
+        check(rc, self.lib)
+
     def close(self):
+        """Closes every live Plan (and their Streams) first: caf_ctx_destroy frees the plans'
+        device buffers, so their Python handles must not outlive it."""
         if getattr(self, "_h", None):
-            self.lib.caf_ctx_destroy(self._h)
+            for p in list(self._plans):
+                p.close()
+            self._check(self.lib.caf_ctx_destroy(self._h))
             self._h = None
 
     def __del__(self):  # best effort
@@ -74,17 +85,17 @@ class Engine:
         """Run on the given hipStream_t handle (0 = HIP's null stream = torch's default
         stream); ``None`` goes back to the context's private stream."""
         if hip_stream is None:
-            check(self.lib.caf_ctx_reset_stream(self._h))
+            self._check(self.lib.caf_ctx_reset_stream(self._h))
         else:
-            check(self.lib.caf_ctx_set_stream(self._h, ctypes.c_void_p(int(hip_stream))))
+            self._check(self.lib.caf_ctx_set_stream(self._h, ctypes.c_void_p(int(hip_stream))))
 
     def synchronize(self):
-        check(self.lib.caf_ctx_synchronize(self._h))
+        self._check(self.lib.caf_ctx_synchronize(self._h))
 
     def device_info(self) -> Tuple[int, str]:
         cu = ctypes.c_int()
         buf = ctypes.create_string_buffer(128)
-        check(self.lib.caf_ctx_device_info(self._h, ctypes.byref(cu), buf, 128))
+        self._check(self.lib.caf_ctx_device_info(self._h, ctypes.byref(cu), buf, 128))
         return cu.value, buf.value.decode()
 
     # -- a1 -----------------------------------------------------------------------
@@ -93,12 +104,12 @@ class Engine:
         if np.asarray(samples).dtype == np.complex64:
             s = _as_c64(samples)
             out = np.empty_like(s)
-            check(self.lib.caf_apply_freq_shift_c64(self._h, _fptr(s.view(np.float32)), len(s),
+            self._check(self.lib.caf_apply_freq_shift_c64(self._h, _fptr(s.view(np.float32)), len(s),
                                                     float(freq_shift), int(fs), _fptr(out.view(np.float32))))
             return out
         s = _as_c128(samples)
         out = np.empty_like(s)
-        check(self.lib.caf_apply_freq_shift_c128(self._h, _dptr(s.view(np.float64)), len(s),
+        self._check(self.lib.caf_apply_freq_shift_c128(self._h, _dptr(s.view(np.float64)), len(s),
                                                  float(freq_shift), int(fs), _dptr(out.view(np.float64))))
         return out
 
@@ -110,12 +121,12 @@ class Engine:
         if np.asarray(a).dtype == np.complex64 and np.asarray(b).dtype == np.complex64:
             a, b = _as_c64(a), _as_c64(b)
             out = np.empty_like(a)
-            check(self.lib.caf_xcor_c64(self._h, _fptr(a.view(np.float32)), _fptr(b.view(np.float32)), len(a),
+            self._check(self.lib.caf_xcor_c64(self._h, _fptr(a.view(np.float32)), _fptr(b.view(np.float32)), len(a),
                                         _fptr(out.view(np.float32))))
             return out
         a, b = _as_c128(a), _as_c128(b)
         out = np.empty_like(a)
-        check(self.lib.caf_xcor_c128(self._h, _dptr(a.view(np.float64)), _dptr(b.view(np.float64)), len(a),
+        self._check(self.lib.caf_xcor_c128(self._h, _dptr(a.view(np.float64)), _dptr(b.view(np.float64)), len(a),
                                      _dptr(out.view(np.float64))))
         return out
 
@@ -134,14 +145,14 @@ class Engine:
             nd, hs = _as_c64(needle), _as_c64(haystack)
             surf = np.empty((F, 2 * n), dtype=np.float32) if want_surface else None
             rval = np.zeros(F, dtype=np.float32)
-            check(self.lib.caf_surface_c64(self._h, _fptr(nd.view(np.float32)), _fptr(hs.view(np.float32)), n,
+            self._check(self.lib.caf_surface_c64(self._h, _fptr(nd.view(np.float32)), _fptr(hs.view(np.float32)), n,
                                            _dptr(fr), F, int(fs), _fptr(surf) if want_surface else None,
                                            _uptr(ridx), _fptr(rval), ctypes.byref(peak)))
         elif dtype == "c128":
             nd, hs = _as_c128(needle), _as_c128(haystack)
             surf = np.empty((F, 2 * n), dtype=np.float64) if want_surface else None
             rval = np.zeros(F, dtype=np.float64)
-            check(self.lib.caf_surface_c128(self._h, _dptr(nd.view(np.float64)), _dptr(hs.view(np.float64)), n,
+            self._check(self.lib.caf_surface_c128(self._h, _dptr(nd.view(np.float64)), _dptr(hs.view(np.float64)), n,
                                             _dptr(fr), F, int(fs), _dptr(surf) if want_surface else None,
                                             _uptr(ridx), _dptr(rval), ctypes.byref(peak)))
         else:
@@ -166,7 +177,7 @@ class Engine:
         ri = np.array([r.xcor_peak_idx for r in arr], dtype=np.uint64)
         rv = np.array([r.xcor_peak_val for r in arr], dtype=np.float64)
         peak = CafPeak()
-        check(self.lib.caf_find_peak(self._h, _dptr(fr), _uptr(ri), _dptr(rv), F, ctypes.byref(peak)))
+        self._check(self.lib.caf_find_peak(self._h, _dptr(fr), _uptr(ri), _dptr(rv), F, ctypes.byref(peak)))
         return float(peak.freq), int(peak.idx)
 
     # -- views in the Go / Python implementations' conventions -----
@@ -180,7 +191,7 @@ class Engine:
         code = {"go": _lib.CAF_VIEW_GO, "python": _lib.CAF_VIEW_PYTHON}[view]
         dt = CAF_C128 if surf.dtype == np.float64 else CAF_C64
         out = np.empty((rows, L if view == "go" else n), dtype=surf.dtype)
-        check(self.lib.caf_surface_view(self._h, dt, ctypes.c_void_p(surf.ctypes.data), rows, n, code,
+        self._check(self.lib.caf_surface_view(self._h, dt, ctypes.c_void_p(surf.ctypes.data), rows, n, code,
                                         ctypes.c_void_p(out.ctypes.data)))
         return out
 
@@ -196,8 +207,13 @@ class Engine:
         r = int(pk.row)
         lo = cf[r - 1] if r > 0 else cf[r] - (cf[1] - cf[0] if len(cf) > 1 else fine_step)
         hi = cf[r + 1] if r + 1 < len(cf) else cf[r] + (cf[-1] - cf[-2] if len(cf) > 1 else fine_step)
-        k0, k1 = int(round(lo / fine_step)), int(round(hi / fine_step))
-        ff = np.array([k * fine_step for k in range(k0, k1 + 1)], dtype=np.float64)
+        # the fine grid is built like gen_float_shifts (test.rs:335-352): integer milli-Hz / 1e3,
+        # so its values are bit-identical to the reference's grids (32.15, not 32.150000000000006)
+        st = int(round(fine_step * 1000.0))
+        if st <= 0:
+            raise ValueError("fine_step must be >= 0.001 Hz (milli-Hz grid, test.rs:341)")
+        k0, k1 = int(round(lo * 1000.0 / st)), int(round(hi * 1000.0 / st))
+        ff = np.array([(k * st) / 1e3 for k in range(k0, k1 + 1)], dtype=np.float64)
         _, _, _, pf = self.surface_arrays(needle, haystack, ff, fs, want_surface=False, dtype=dtype)
         return (float(pk.freq), int(pk.idx)), (float(pf.freq), int(pf.idx)), ff
 
@@ -221,9 +237,11 @@ class Plan:
         self.dtype = dtype
         dt = {"c128": CAF_C128, "c64": CAF_C64}[dtype]
         h = ctypes.c_void_p()
-        check(eng.lib.caf_plan_create(eng._h, int(n), _dptr(fr), len(fr), int(fs), dt, int(row_begin),
+        eng._check(eng.lib.caf_plan_create(eng._h, int(n), _dptr(fr), len(fr), int(fs), dt, int(row_begin),
                                       int(row_end), ctypes.byref(h)))
         self._h = h
+        self._streams = weakref.WeakSet()
+        eng._plans.add(self)
         self.n, self.L = int(n), 2 * int(n)
         self.rows = int(eng.lib.caf_plan_rows(h))
         self.row_begin = int(row_begin)
@@ -232,22 +250,25 @@ class Plan:
 
     def surface_dev(self, d_needle: int, d_haystack: int, batch: int, d_surface: Optional[int], d_row_idx: int,
                     d_row_val: int, d_peak: int):
-        check(self.eng.lib.caf_surface_dev(self._h, ctypes.c_void_p(d_needle), ctypes.c_void_p(d_haystack),
+        self.eng._check(self.eng.lib.caf_surface_dev(self._h, ctypes.c_void_p(d_needle), ctypes.c_void_p(d_haystack),
                                            int(batch), ctypes.c_void_p(d_surface or 0), ctypes.c_void_p(d_row_idx),
                                            ctypes.c_void_p(d_row_val), ctypes.c_void_p(d_peak)))
 
     def timing_begin(self):
-        check(self.eng.lib.caf_plan_timing_begin(self._h))
+        self.eng._check(self.eng.lib.caf_plan_timing_begin(self._h))
 
     def timing_end(self) -> Tuple[float, int]:
         ms = ctypes.c_double()
         n = ctypes.c_uint64()
-        check(self.eng.lib.caf_plan_timing_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        self.eng._check(self.eng.lib.caf_plan_timing_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, int(n.value)
 
     def close(self):
+        """Closes the plan's Streams first (their graphs hold the plan's device buffers)."""
         if getattr(self, "_h", None) and getattr(self.eng, "_h", None):
-            self.eng.lib.caf_plan_destroy(self._h)
+            for st in list(self._streams):
+                st.close()
+            self.eng._check(self.eng.lib.caf_plan_destroy(self._h))
         self._h = None
 
     def __del__(self):
@@ -260,37 +281,40 @@ class Plan:
 class Stream:
     """``caf_stream``: double-buffered streaming of host-resident pairs (BASELINE configs[4]).
     ``buffers(slot)`` are numpy views of the slot's PINNED staging memory; fill them, then
-    ``submit(slot)`` (asynchronous graph replay) and later ``wait(slot)``."""
+    ``submit(slot)`` (asynchronous graph replay) and later ``wait(slot)``.  The views keep the
+    Stream object alive, but an explicit ``close()`` frees the pinned memory under them."""
 
     PEAK_DTYPE = np.dtype([("val", "<f8"), ("freq", "<f8"), ("idx", "<u8"), ("row", "<i8")])
 
     def __init__(self, plan: "Plan", batch: int, nslots: int = 2, want_surface: bool = True):
         self.plan, self.batch, self.nslots = plan, int(batch), int(nslots)
         h = ctypes.c_void_p()
-        check(plan.eng.lib.caf_stream_create(plan._h, self.batch, self.nslots, int(bool(want_surface)),
+        plan.eng._check(plan.eng.lib.caf_stream_create(plan._h, self.batch, self.nslots, int(bool(want_surface)),
                                              ctypes.byref(h)))
         self._h = h
+        plan._streams.add(self)
         self._cdt = np.complex128 if plan.dtype == "c128" else np.complex64
         self._rdt = np.float64 if plan.dtype == "c128" else np.float32
 
     def buffers(self, slot: int):
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
-        check(self.plan.eng.lib.caf_stream_host_buffers(self._h, int(slot), ctypes.byref(a), ctypes.byref(b)))
+        self.plan.eng._check(self.plan.eng.lib.caf_stream_host_buffers(self._h, int(slot), ctypes.byref(a), ctypes.byref(b)))
         nbytes = self.batch * self.plan.n * np.dtype(self._cdt).itemsize
 
         def view(p):
             buf = (ctypes.c_char * nbytes).from_address(p.value)
+            buf._caf_owner = self  # the view's base keeps the Stream (and its pinned memory) alive
             return np.frombuffer(buf, dtype=self._cdt).reshape(self.batch, self.plan.n)
         return view(a), view(b)
 
     def submit(self, slot: int):
-        check(self.plan.eng.lib.caf_stream_submit(self._h, int(slot)))
+        self.plan.eng._check(self.plan.eng.lib.caf_stream_submit(self._h, int(slot)))
 
     def wait(self, slot: int, want_rows: bool = True):
         peaks = np.zeros(self.batch, dtype=self.PEAK_DTYPE)
         ridx = np.zeros((self.batch, self.plan.rows), dtype=np.uint64) if want_rows else None
         rval = np.zeros((self.batch, self.plan.rows), dtype=self._rdt) if want_rows else None
-        check(self.plan.eng.lib.caf_stream_wait(
+        self.plan.eng._check(self.plan.eng.lib.caf_stream_wait(
             self._h, int(slot), peaks.ctypes.data_as(ctypes.POINTER(CafPeak)),
             _uptr(ridx) if want_rows else None, ctypes.c_void_p(rval.ctypes.data) if want_rows else None))
         return peaks, ridx, rval

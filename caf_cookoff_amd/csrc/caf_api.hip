@@ -16,10 +16,16 @@
 #include "kernels_fused4096.hpp"
 #include "kernels_seq4096.hpp"
 #include "kernels_duo4096.hpp"
-#include "kernels_r8_4096.hpp"
 #include "kernels_big65536.hpp"
-#include "kernels_q65536.hpp"
 #include "kernels_generic.hpp"
+// Measurement build (-DCAF_MEASURE -> libcaf_hip_measure.so, used by tools/ and the variant
+// tests only): rejected kernel variants, ablation instantiations that produce WRONG results and
+// the environment switches that select them.  The product library contains none of it and reads
+// no environment variable.
+#ifdef CAF_MEASURE
+#include "kernels_r8_4096.hpp"
+#include "kernels_q65536.hpp"
+#endif
 
 using namespace caf;
 
@@ -44,6 +50,16 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 #define KCHK() HIPCHK(hipGetLastError())
+
+#ifdef CAF_MEASURE
+static long measure_env(const char *name, long dflt)
+{
+    const char *v = getenv(name);
+    return v ? atol(v) : dflt;
+}
+#else
+static constexpr long measure_env(const char *, long dflt) { return dflt; }
+#endif
 
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 static size_t elem_size(int dtype) { return dtype == CAF_C128 ? 16 : 8; }
@@ -84,6 +100,7 @@ struct caf_ctx {
     DevBuf io_needle, io_hay, io_surface, io_ridx, io_rval, io_peak, io_a, io_b;
     caf_plan *cached = nullptr;
     std::vector<double> cached_freqs;
+    std::vector<caf_plan *> plans;  // every live plan of this context (destroyed with it)
 };
 
 struct caf_plan {
@@ -105,8 +122,10 @@ struct caf_plan {
     // generic
     void *d_tw = nullptr;  // borrowed from ctx cache
     DevBuf wx, wy, hx, hy;
-    unsigned long long *dbg = nullptr;  // diagnostic stamps buffer (caf_debug_set_stamps)
-    int variant = 0;                    // row kernel of n = 4096 plans: 0 sequential chains, 3 two chains in flight; 1, 2: measurement variants
+    unsigned long long *dbg = nullptr;  // measurement build: diagnostic stamps buffer (caf_debug_set_stamps)
+    size_t dbg_len = 0;                 //   ... its length in u64
+    int variant = 0;                    // row kernel of n = 4096 plans: 0 sequential chains, 3 two chains in flight; 1, 2: measurement build only
+    int live_streams = 0;               // caf_stream objects whose graphs hold this plan's buffers
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -202,9 +221,13 @@ extern "C" int caf_plan_destroy(caf_plan *p);
 extern "C" int caf_ctx_destroy(caf_ctx *c)
 {
     if (!c) return CAF_OK;
+    for (caf_plan *p : c->plans)
+        if (p->live_streams)
+            return fail(CAF_ERR_STATE, "caf_ctx_destroy: a plan still has %d live caf_stream(s); destroy them first",
+                        p->live_streams);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->cached) caf_plan_destroy(c->cached);
+    while (!c->plans.empty()) caf_plan_destroy(c->plans.back());  // user plans too: their tables live in this context
     for (int d = 0; d < 2; ++d) {
         if (c->tw4096[d]) (void)hipFree(c->tw4096[d]);
         if (c->th[d]) (void)hipFree(c->th[d]);
@@ -339,6 +362,7 @@ static int plan_build_tables(caf_plan *p)
     caf_ctx *c = p->ctx;
     const int dt = p->dtype;
     int rc;
+#ifdef CAF_MEASURE
     if (p->big && p->bigq) {
         if ((rc = build_fused_tables<T>(c, dt))) return rc;  // W_4096 for the 4096-point chains
         if (!c->qoutw[dt]) {
@@ -351,7 +375,10 @@ static int plan_build_tables(caf_plan *p)
         k_q_phasors<T><<<(unsigned)((nr * 1024 + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows,
                                                                                  (cpx<T> *)p->d_phasor);
         KCHK();
-    } else if (p->big) {
+        return CAF_OK;
+    }
+#endif
+    if (p->big) {
         if (!c->bigw256[dt]) {
             HIPCHK(hipMalloc(&c->bigw256[dt], 256 * sizeof(cpx<T>)));
             HIPCHK(hipMalloc(&c->bigwL[dt], 256 * sizeof(cpx<T>)));
@@ -368,10 +395,12 @@ static int plan_build_tables(caf_plan *p)
         const size_t nr = p->rows + 1;  // +1: the f = 0 row for the haystack transform
         HIPCHK(hipMalloc(&p->d_phasor, nr * 64 * sizeof(cpx<T>)));
         const size_t threads = nr * 64;
+#ifdef CAF_MEASURE
         if (p->variant == 2)
             k_r8_phasors<T><<<(unsigned)((threads + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows,
                                                                                        (cpx<T> *)p->d_phasor);
         else
+#endif
             k_fused_phasors<T><<<(unsigned)((threads + 255) / 256), 256, 0, c->stream>>>(
                 p->d_ph, (int)p->rows, (cpx<T> *)p->d_phasor);
         KCHK();
@@ -406,10 +435,16 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     p->rows = row_end - row_begin;
     p->fused = (n == (size_t)F_N);
     p->big = (n == (size_t)B_N);
-    // CAF_BIG_PATH=1: the 16 x 4096 two-pass form (parity-green, 2.63 vs 2.19 ms per 4096-row surface)
-    p->bigq = p->big && getenv("CAF_BIG_PATH") && atoi(getenv("CAF_BIG_PATH")) == 1;
     p->variant = dtype == CAF_C64 ? 3 : 0;  // f32: two chains in flight; f64: sequential chains (kernels_duo4096.hpp)
-    if (const char *ev = getenv("CAF_ROW_KERNEL")) p->variant = atoi(ev);
+    // measurement build only: CAF_BIG_PATH=1 = the 16 x 4096 two-pass form (parity-green, 2.63 vs 2.19 ms per
+    // 4096-row surface); CAF_ROW_KERNEL = 0..3 picks the n = 4096 row kernel.  No-ops in the product library.
+    p->bigq = p->big && measure_env("CAF_BIG_PATH", 0) == 1;
+    p->variant = (int)measure_env("CAF_ROW_KERNEL", p->variant);
+    if (p->variant < 0 || p->variant > 3) {
+        const int bad = p->variant;
+        delete p;
+        return fail(CAF_ERR_BAD_ARG, "CAF_ROW_KERNEL=%d: no such row kernel", bad);
+    }
     int rc = CAF_OK;
     auto bail = [&](int code) { caf_plan_destroy(p); return code; };
     if (p->rows) {
@@ -429,6 +464,7 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     if (rc) return bail(rc);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return bail(fail(CAF_ERR_HIP, "plan tables: %s", hipGetErrorString(e)));
+    c->plans.push_back(p);
     *out = p;
     return CAF_OK;
 }
@@ -436,8 +472,13 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
 extern "C" int caf_plan_destroy(caf_plan *p)
 {
     if (!p) return CAF_OK;
+    // the captured graphs of a caf_stream hold raw pointers into this plan's tables and workspaces
+    if (p->live_streams)
+        return fail(CAF_ERR_STATE, "caf_plan_destroy: %d caf_stream(s) of this plan are still alive", p->live_streams);
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
+    for (auto it = p->ctx->plans.begin(); it != p->ctx->plans.end(); ++it)
+        if (*it == p) { p->ctx->plans.erase(it); break; }
     if (p->d_freqs) (void)hipFree(p->d_freqs);
     if (p->d_ph) (void)hipFree(p->d_ph);
     if (p->d_phasor) (void)hipFree(p->d_phasor);
@@ -458,7 +499,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
 {
     if (!p) return "";
     const bool f64 = p->dtype == CAF_C128;
-    if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";
+    if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";  // measurement build
     if (p->big) return f64 ? "caf::k_big_rows<double>" : "caf::k_big_rows<float>";
     if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
     if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0, 15>" : "caf::k_seq_rows<float, 0, 0, 15>";
@@ -505,14 +546,28 @@ extern "C" int caf_plan_timing_end(caf_plan *p, double *ms_total, uint64_t *laun
     return CAF_OK;
 }
 
-// Internal (not in include/caf_hip.h): route the next caf_surface_dev calls of a fused
-// plan through the stamped DIAG instantiation; d_buf = 32*8*F_NSTAMP u64 or NULL to stop.
-extern "C" int caf_debug_set_stamps(caf_plan *p, void *d_buf)
+#ifdef CAF_MEASURE
+// Measurement build only (not in include/caf_hip.h): route the next caf_surface_dev calls of an
+// n = 4096 plan through a stamped DIAG instantiation.  d_buf = `len_u64` device u64 words or NULL to
+// stop.  Variant 0 (k_seq_rows<T,0,8,15>) writes 32*4*S_NSTAMP stamp words plus 4 words per
+// workgroup of the launch; variant 1 (k_fused_rows<T,true>) writes 32*8*F_NSTAMP words.  The other
+// variants have no DIAG build.
+extern "C" int caf_debug_set_stamps(caf_plan *p, void *d_buf, size_t len_u64)
 {
     if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
+    if (d_buf) {
+        if (!p->fused || (p->variant != 0 && p->variant != 1))
+            return fail(CAF_ERR_BAD_ARG, "caf_debug_set_stamps: row kernel variant %d has no stamped build", p->variant);
+        const size_t max_grid = (size_t)p->ctx->cu_count * 8;
+        const size_t need = p->variant == 0 ? (size_t)32 * 4 * S_NSTAMP + 4 * max_grid : (size_t)32 * 8 * F_NSTAMP;
+        if (len_u64 < need)
+            return fail(CAF_ERR_BAD_ARG, "caf_debug_set_stamps: buffer of %zu u64 words, %zu needed", len_u64, need);
+    }
     p->dbg = (unsigned long long *)d_buf;
+    p->dbg_len = d_buf ? len_u64 : 0;
     return CAF_OK;
 }
+#endif
 
 // ------------------------------------------------------------ surface (dev) --
 template <typename T>
@@ -536,59 +591,57 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     // xcor_rustfft.rs:58-59)
     a.sig = (const cpx<T> *)d_hay;
     a.total = (int)batch;
-    const unsigned prep_grid = (unsigned)(batch < (size_t)c->cu_count ? batch : (size_t)c->cu_count);
+#ifdef CAF_MEASURE
     if (p->variant == 2) {
+        const unsigned prep_grid = (unsigned)(batch < (size_t)c->cu_count ? batch : (size_t)c->cu_count);
         k_r8_prepare<T><<<prep_grid, R_THREADS, 0, c->stream>>>(a);
-    } else {  // one workgroup per (surface, chain): halves the latency of a single-surface call
+    } else
+#endif
+    {  // one workgroup per (surface, chain): halves the latency of a single-surface call
         const size_t want = 2 * batch, cap2 = 2 * (size_t)c->cu_count;
         k_seq_prepare<T><<<(unsigned)(want < cap2 ? want : cap2), S_THREADS, 0, c->stream>>>(a, a.phasor);
     }
     KCHK();
     const size_t total = batch * p->rows;
     if (total == 0) return CAF_OK;
-    static const bool static_rows = getenv("CAF_STATIC_ROWS") != nullptr;  // measurement: static striding
     // Dynamic row tickets pay off from ~6 rows per resident workgroup; below that the static
     // stride (no atomic, no LDS round trip per row) is 2-7 % faster (measured at batch 1-16).
-    if (static_rows || total <= 4 * (size_t)c->cu_count * 2) a.work = nullptr;
+    // (CAF_STATIC_ROWS, measurement build: static striding for every launch size.)
+    if (measure_env("CAF_STATIC_ROWS", 0) || total <= 4 * (size_t)c->cu_count * 2) a.work = nullptr;
     a.sig = (const cpx<T> *)d_needle;
     a.total = (int)total;
     a.surface = (T *)d_surface;
     a.row_idx = d_ridx;
     a.row_val = (T *)d_rval;
     if ((rc = timing_mark(p))) return rc;
+    // resident workgroups per CU: LDS- and VGPR-limited (2 in f64, 3 in f32)
+    size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
+    if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();
+    if (measure_env("CAF_WG_PER_CU", 0) > 0) per_cu = (size_t)measure_env("CAF_WG_PER_CU", 0);
+    const size_t cap = (size_t)c->cu_count * per_cu;
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
+#ifdef CAF_MEASURE
+    const int store_mode = (int)measure_env("CAF_STORE_MODE", 0);
     if (p->variant == 2) {
-        const size_t cap = (size_t)c->cu_count * 2;
-        const unsigned grid = (unsigned)(total < cap ? total : cap);
-        static const int r8_nostore = getenv("CAF_STORE_MODE") ? atoi(getenv("CAF_STORE_MODE")) == 3 : 0;
-        if (r8_nostore)
-            k_r8_rows<T, 3><<<grid, R_THREADS, 0, c->stream>>>(a);
+        const size_t cap8 = (size_t)c->cu_count * 2;
+        const unsigned g8 = (unsigned)(total < cap8 ? total : cap8);
+        if (store_mode == 3)
+            k_r8_rows<T, 3><<<g8, R_THREADS, 0, c->stream>>>(a);
         else
-            k_r8_rows<T, 0><<<grid, R_THREADS, 0, c->stream>>>(a);
-    } else if (p->variant == 3) {
-        size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
-        if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();
-        const size_t cap = (size_t)c->cu_count * per_cu;
-        const unsigned grid = (unsigned)(total < cap ? total : cap);
-        static const int duo_nostore = getenv("CAF_STORE_MODE") ? atoi(getenv("CAF_STORE_MODE")) == 3 : 0;
-        if (duo_nostore)
-            k_duo_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
+            k_r8_rows<T, 0><<<g8, R_THREADS, 0, c->stream>>>(a);
+    } else if (p->variant == 1) {
+        const size_t capf = (size_t)c->cu_count * (fused_lds_bytes<T>() * 2 <= 160 * 1024 ? 2 : 1);
+        const unsigned gf = (unsigned)(total < capf ? total : capf);
+        if (p->dbg)
+            k_fused_rows<T, true><<<gf, F_THREADS, 0, c->stream>>>(a);
         else
-            k_duo_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
+            k_fused_rows<T, false><<<gf, F_THREADS, 0, c->stream>>>(a);
+    } else if (p->variant == 3 && store_mode == 3) {
+        k_duo_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
     } else if (p->variant == 0 && p->dbg) {
-        size_t per_cu = 2;
-        static const int wg_env = getenv("CAF_WG_PER_CU") ? atoi(getenv("CAF_WG_PER_CU")) : 0;
-        if (wg_env > 0) per_cu = (size_t)wg_env;
-        const size_t cap = (size_t)c->cu_count * per_cu;
-        k_seq_rows<T, 0, 8, 15><<<(unsigned)(total < cap ? total : cap), S_THREADS, 0, c->stream>>>(a, a.phasor);
-    } else if (p->variant == 0 && !p->dbg) {
-        size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
-        if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();  // VGPR-limited
-        static const int wg_per_cu_env = getenv("CAF_WG_PER_CU") ? atoi(getenv("CAF_WG_PER_CU")) : 0;  // measurement only
-        if (wg_per_cu_env > 0) per_cu = (size_t)wg_per_cu_env;
-        const size_t cap = (size_t)c->cu_count * per_cu;
-        const unsigned grid = (unsigned)(total < cap ? total : cap);
-        static const int store_mode = getenv("CAF_STORE_MODE") ? atoi(getenv("CAF_STORE_MODE")) : 0;
-        switch (store_mode) {  // 1-3: measurement variants only
+        k_seq_rows<T, 0, 8, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
+    } else if (p->variant == 0 && store_mode != 0) {
+        switch (store_mode) {  // measurement variants; 3, 5, 11-13, 31-35 produce WRONG results (timing only)
         case 1: k_seq_rows<T, 1><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         case 2: k_seq_rows<T, 2><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
         case 3: k_seq_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
@@ -604,22 +657,20 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
         case 34: k_seq_rows<T, 3, 1, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS, no stores
         case 35: k_seq_rows<T, 3, 2, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no loads, no stores
         case 21: k_seq_rows<T, 0, 0, 31><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // deferred argmax publish
-        default: k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
+        default: return fail(CAF_ERR_BAD_ARG, "CAF_STORE_MODE=%d: no such measurement mode", store_mode);
         }
-    } else {
-        const size_t per_cu = fused_lds_bytes<T>() * 2 <= 160 * 1024 ? 2 : 1;
-        const size_t cap = (size_t)c->cu_count * per_cu;
-        const unsigned grid = (unsigned)(total < cap ? total : cap);
-        if (p->dbg)
-            k_fused_rows<T, true><<<grid, F_THREADS, 0, c->stream>>>(a);
-        else
-            k_fused_rows<T, false><<<grid, F_THREADS, 0, c->stream>>>(a);
-    }
+    } else
+#endif
+    if (p->variant == 3)
+        k_duo_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex64 product kernel
+    else
+        k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex128 product kernel
     KCHK();
     if ((rc = timing_mark(p))) return rc;
     return CAF_OK;
 }
 
+#ifdef CAF_MEASURE
 // n = 32768 as 16 x 4096: two passes (kernels_q65536.hpp)
 template <typename T>
 static int surface_dev_q(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
@@ -653,7 +704,7 @@ static int surface_dev_q(caf_plan *p, const void *d_needle, const void *d_hay, s
     KCHK();
     if (total == 0) return CAF_OK;
     // chunks of rows share one Infinity-Cache-resident work buffer (see surface_dev_big)
-    static const size_t chunk_env = getenv("CAF_BIG_CHUNK") ? (size_t)atol(getenv("CAF_BIG_CHUNK")) : 0;
+    const size_t chunk_env = (size_t)measure_env("CAF_BIG_CHUNK", 0);  // measurement build only
     size_t chunk = chunk_env ? chunk_env : (128u << 20) / (B_L * sizeof(cpx<T>));
     if (chunk < 1) chunk = 1;
     if (chunk > 32768) chunk = 32768;
@@ -683,6 +734,7 @@ static int surface_dev_q(caf_plan *p, const void *d_needle, const void *d_hay, s
     if ((rc = timing_mark(p))) return rc;
     return CAF_OK;
 }
+#endif  // CAF_MEASURE
 
 // n = 32768: four-step tiled path (kernels_big65536.hpp)
 template <typename T>
@@ -702,7 +754,7 @@ static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay,
     a.rows = (int)rows;
     a.surface = nullptr; a.part_val = nullptr; a.part_idx = nullptr;
     // persistent launches: 16 tiles x gy_cap rows of workgroups ~ one resident set; each loops over its rows
-    static const size_t gy_env = getenv("CAF_BIG_GY") ? (size_t)atol(getenv("CAF_BIG_GY")) : 0;
+    const size_t gy_env = (size_t)measure_env("CAF_BIG_GY", 0);  // measurement build only
     const size_t gy_cap = gy_env ? gy_env : (size_t)c->cu_count * 3 / 16;  // 2.19-2.26 ms per 4096-row surface for 32...96
     // haystack spectrum once per surface
     a.prepare = 1;
@@ -722,7 +774,7 @@ static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay,
     // Infinity Cache, and every chunk reuses the SAME work buffer: the two intermediate passes
     // hit on-die, and the intermediate data is overwritten in the cache instead of being
     // written back to HBM once per row.
-    static const size_t chunk_env = getenv("CAF_BIG_CHUNK") ? (size_t)atol(getenv("CAF_BIG_CHUNK")) : 0;
+    const size_t chunk_env = (size_t)measure_env("CAF_BIG_CHUNK", 0);  // measurement build only
     size_t chunk = chunk_env ? chunk_env : (128u << 20) / (B_L * sizeof(cpx<T>));
     if (chunk < 1) chunk = 1;
     if (chunk > 32768) chunk = 32768;
@@ -815,12 +867,16 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
     int rc;
     if (p->dtype == CAF_C128)
         rc = p->fused ? surface_dev_fused<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+#ifdef CAF_MEASURE
              : p->big && p->bigq ? surface_dev_q<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+#endif
              : p->big ? surface_dev_big<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
                       : surface_dev_generic<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     else
         rc = p->fused ? surface_dev_fused<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+#ifdef CAF_MEASURE
              : p->big && p->bigq ? surface_dev_q<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+#endif
              : p->big ? surface_dev_big<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
                       : surface_dev_generic<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     if (rc) return rc;
@@ -979,6 +1035,7 @@ struct StreamSlot {
 struct caf_stream {
     caf_plan *plan = nullptr;
     size_t batch = 0;
+    bool counted = false;  // registered in plan->live_streams
     std::vector<StreamSlot> slots;
 };
 
@@ -995,6 +1052,7 @@ static void stream_free(caf_stream *st)
             if (p) (void)hipFree(p);
         if (s.stream && s.own_stream) (void)hipStreamDestroy(s.stream);
     }
+    if (st->counted && st->plan) --st->plan->live_streams;
     delete st;
 }
 
@@ -1082,6 +1140,8 @@ extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want
     p->timing = was_timing;
 #undef SCHK
     c->stream = saved;
+    st->counted = true;
+    ++p->live_streams;  // caf_plan_destroy / caf_ctx_destroy refuse while the graphs hold the plan's buffers
     *out = st;
     return CAF_OK;
 }

@@ -72,6 +72,8 @@ int caf_device_count(void);
 
 /* ---- context ----------------------------------------------------------- */
 int caf_ctx_create(int device_id, caf_ctx **out);
+/* Destroys the context AND every plan created from it that is still alive (their handles
+ * become invalid); CAF_ERR_STATE if one of those plans still has a live caf_stream. */
 int caf_ctx_destroy(caf_ctx *ctx);
 /* Run all work of this context on a caller-owned hipStream_t, e.g. torch's current
  * stream.  The handle is used as given: NULL is HIP's null (legacy default) stream, which
@@ -177,7 +179,15 @@ int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, 
  * row kernel, find_peak, D2H of the row peaks + caf_peak records}.  While slot k computes,
  * the caller fills slot k+1's pinned buffers and submits it: its H2D overlaps slot k's
  * kernels.  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
- * only (tau, f) + per-row peaks come back, as SURVEY.md section 8d prescribes. */
+ * only (tau, f) + per-row peaks come back, as SURVEY.md section 8d prescribes.
+ * Plans whose row kernel keeps its intermediate data on-chip ("fused4096", "chain") give
+ * every slot private device state, so slots execute concurrently.  Plans on the "tiled65536"
+ * and "generic" paths share the plan's pass workspaces: their slots run on ONE stream, in
+ * submit order (slot k+1's H2D waits for slot k's kernels).
+ * Lifetime: the captured graphs hold pointers into the plan's tables and workspaces;
+ * caf_plan_destroy and caf_ctx_destroy return CAF_ERR_STATE while a caf_stream of the plan
+ * is alive -- destroy streams first, then plans, then the context (caf_ctx_destroy itself
+ * destroys every plan that is still alive). */
 typedef struct caf_stream caf_stream;
 int caf_stream_create(caf_plan *plan, size_t batch, int nslots, int want_surface, caf_stream **out);
 int caf_stream_destroy(caf_stream *st);

@@ -122,9 +122,12 @@ def np_caf_surface(needle, haystack, freqs_hz, fs, want_surface=True):
         C = (H * np.conj(np.fft.fft(s))) / L
         c = np.fft.ifft(C) * L
         mag = c.real * c.real + c.imag * c.imag
-        k = int(np.argmax(mag)) if L else 0  # first max == first strictly-greater
-        if L and mag[k] > 0.0:
-            ridx[r], rval[r] = k, mag[k]
+        # first max == first strictly-greater; a NaN never satisfies `>` (mod.rs:148), so it can
+        # neither win nor block a later finite value
+        cand = np.where(np.isnan(mag), -np.inf, mag)
+        k = int(np.argmax(cand)) if L else 0
+        if L and cand[k] > 0.0:
+            ridx[r], rval[r] = k, cand[k]
         if want_surface:
             surf[r] = mag
     return surf, ridx, rval

@@ -1,0 +1,59 @@
+"""bench.py's control path on CPU (no GPU): `--gpus N` outside torchrun must start the N ranks as a
+CHILD process tree, rendezvous, reduce shard peaks with the product's reduce_global_peak and relay
+rank 0's single JSON line; a --gpus / WORLD_SIZE mismatch must exit non-zero."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(args, env_extra=None, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, env=env,
+                          timeout=timeout, cwd=ROOT)
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def test_self_launch_two_ranks_plumbing_only():
+    for method in ("allreduce", "allgather"):
+        r = _run(["--gpus", "2", "--steps", "3", "--plumbing-only", "--peak-reduce", method])
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = _json_lines(r.stdout)
+        assert len(lines) == 1, r.stdout                     # exactly ONE line, from rank 0
+        assert lines[0]["n_gpus"] == 2 and lines[0]["plumbing_only"] and lines[0]["peak_reduce"] == method
+
+
+def test_single_rank_plumbing_needs_no_launcher():
+    r = _run(["--plumbing-only", "--steps", "2"])
+    assert r.returncode == 0 and _json_lines(r.stdout)[0]["n_gpus"] == 1
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "2", "--plumbing-only"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
+    r = _run(["--gpus", "1", "--plumbing-only"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode == 2
+
+
+def test_algorithmic_bytes_match_survey_8d():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    # one surface per launch, freq list included
+    assert bench.algorithmic_bytes(1, 400, 4096, "c128") == 26_355_072
+    assert bench.algorithmic_bytes(1, 400, 4096, "c64") == 13_180_736
+    assert bench.algorithmic_bytes(1, 4096, 32768, "c64") == 1_074_348_032
+    # per additional surface of a batched launch (the freq list is read once per launch)
+    per128 = bench.algorithmic_bytes(2, 400, 4096, "c128") - bench.algorithmic_bytes(1, 400, 4096, "c128")
+    per64 = bench.algorithmic_bytes(2, 400, 4096, "c64") - bench.algorithmic_bytes(1, 400, 4096, "c64")
+    assert per128 == 65_536 + 65_536 + 26_214_400 + 6_400
+    assert per64 == 2 * 32_768 + 13_107_200 + 400 * 12
+    big = bench.algorithmic_bytes(2, 4096, 32768, "c64") - bench.algorithmic_bytes(1, 4096, 32768, "c64")
+    assert big == 2 * 262_144 + 4096 * 65536 * 4 + 4096 * 12
+    assert len(bench.kernel_source_hash()) == 16

@@ -30,6 +30,17 @@ def eng():
     e.close()
 
 
+@pytest.fixture(scope="module")
+def meng():
+    """Engine on the MEASUREMENT build (libcaf_hip_measure.so): rejected kernel variants and the
+    CAF_* environment switches live only there."""
+    import caf_cookoff_amd as caf
+    assert caf.MEASURE_LIB_PATH.exists(), "measurement library missing (make -C caf_cookoff_amd/csrc)"
+    e = caf.Engine(0, lib=caf.MEASURE_LIB_PATH)
+    yield e
+    e.close()
+
+
 def _pair(oracle, k):
     return oracle.load_pair(DATA, f"chirp_{k}_raw.c64", oracle.KATS[k][1])
 
@@ -195,9 +206,13 @@ def test_edge_cases(eng, oracle):
     d[0] = 1.0
     h = np.zeros(4096, dtype=np.complex128)
     h[100] = 2.0
-    h[300] = 2.0  # two (nearly) equal peaks: the row argmax is the FIRST maximum of the stored row
+    h[300] = 2.0  # two (nearly) equal peaks: the row argmax is the FIRST lag that attains the row maximum
     surf, ridx, rval, peak = eng.surface_arrays(d, h, np.array([0.0]), FS)
-    assert int(ridx[0]) in (100, 300) and int(ridx[0]) == int(np.argmax(surf[0])) and abs(rval[0] - 4.0) < 1e-12
+    first_max = int(np.flatnonzero(surf[0] == surf[0].max())[0])          # mod.rs:148-151: strict '>' scan
+    assert int(ridx[0]) == first_max and rval[0] == surf[0, first_max] and abs(rval[0] - 4.0) < 1e-12
+    if surf[0, 100] == surf[0, 300]:                                      # bitwise tie: the lower lag must win
+        assert int(ridx[0]) == 100
+    assert {first_max} <= {100, 300}
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
@@ -410,10 +425,11 @@ def test_ragged_shard_batches_both_row_assignments(eng, oracle):
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3], ids=["sequential", "lane-half", "radix8", "two-chain"])
-def test_row_kernel_variants_agree(variant, eng, oracle, golden, monkeypatch):
-    """All four n = 4096 row kernels (CAF_ROW_KERNEL) produce the reference's
-    answer: the product uses 0 for complex128 and 3 for complex64, the others are measurement
-    variants and must stay parity-green."""
+def test_row_kernel_variants_agree(variant, meng, oracle, golden, monkeypatch):
+    """All four n = 4096 row kernels (CAF_ROW_KERNEL of the MEASUREMENT library)
+    produce the reference's answer: the product uses 0 for complex128 and 3 for complex64, the
+    others are measurement variants and must stay parity-green."""
+    eng = meng
     monkeypatch.setenv("CAF_ROW_KERNEL", str(variant))
     fr = oracle.bench_shifts()
     nd, hs = _pair(oracle, 0)
@@ -543,10 +559,11 @@ def test_L65536_c128_tiled_path_and_negative_lag(eng, oracle):
     plan.close()
 
 
-def test_L65536_two_pass_variant(eng, oracle, monkeypatch):
-    """CAF_BIG_PATH=1: the 16 x 4096 two-pass form of the n = 32768 row (kernels_q65536.hpp) against
-    the numpy oracle, complex64 and complex128."""
+def test_L65536_two_pass_variant(meng, oracle, monkeypatch):
+    """CAF_BIG_PATH=1 (measurement library): the 16 x 4096 two-pass form of the n = 32768 row
+    (kernels_q65536.hpp) against the numpy oracle, complex64 and complex128."""
     from caf_cookoff_amd.synth import make_pair
+    eng = meng
     monkeypatch.setenv("CAF_BIG_PATH", "1")
     n = 32768
     fr = np.array([11.5, 12.0, 12.5, -3.0])
@@ -619,6 +636,28 @@ def test_go_and_python_views(eng, oracle):
     assert (n - tdx, fr[fdx]) == (peak.idx, peak.freq) == (70, 83.0)
     fdx, tmax = np.unravel_index(np.argmax(py), py.shape)
     assert (n // 2 - tmax, fr[fdx]) == (70, 83.0)
+
+
+def test_python_view_vs_reference_amb_surf_fixture(eng, oracle):
+    """CAF_VIEW_PYTHON against the output of the reference's OWN caf_python/caf.py amb_surf
+    (caf.py:89-117) on its __main__ pair (caf.py:126-133), stored by tests/golden/make_py_fixture.py.
+    The reference computes in complex64 (np.empty_like(ray), caf.py:30; scipy correlate keeps
+    single precision): tolerance 2e-6 of the surface maximum (measured 2.1e-7)."""
+    from conftest import GOLDEN
+    g = np.load(GOLDEN / "py_amb_surf.npz")
+    nd, hs = oracle.load_pair(DATA, str(g["needle"]), str(g["haystack"]))
+    fr = g["freqs"]
+    assert np.array_equal(fr, oracle.bench_shifts())  # np.arange(-100, 100, .5) == the Rust bench grid
+    surf, ridx, rval, peak = eng.surface_arrays(nd, hs, fr, FS)
+    py = eng.surface_view(surf, "python")
+    assert py.shape == tuple(g["shape"])
+    tol = 2e-6 * g["row_max"].max()
+    assert np.max(np.abs(py[g["full_rows"]] - g["rows"])) <= tol
+    assert np.max(np.abs(py.reshape(-1)[::int(g["stride"])] - g["strided"])) <= tol
+    assert np.max(np.abs(py.max(axis=1) - g["row_max"])) <= tol
+    fmax, tmax = np.unravel_index(py.argmax(), py.shape)                  # caf.py:144-146
+    assert (len(nd) // 2 - tmax, fr[fmax]) == (int(g["tau"]), float(g["freq"])) == (70, 83.0)
+    assert (peak.idx, peak.freq) == (70, 83.0)
 
 
 def test_refine_peak_coarse_to_fine(eng, oracle):

@@ -3,7 +3,7 @@ reference's own tests hold for this path: caf_rust/tests/test.rs:14-316."""
 import numpy as np
 import pytest
 
-from conftest import DATA
+from conftest import DATA, GOLDEN
 
 FS = 48000
 
@@ -121,3 +121,43 @@ def test_edge_cases(oracle, coracle):
     # gen_float_shifts truncation semantics (test.rs:341-343)
     assert len(oracle.gen_float_shifts(30.0, 35.0, 0.05)) == 100
     assert oracle.gen_float_shifts(80.0, 100.0, 0.1)[29] == 82.9
+
+
+def test_python_reference_fixture_pins_the_python_view(oracle):
+    """tests/golden/py_amb_surf.npz holds outputs of the reference's OWN caf_python/caf.py amb_surf
+    (caf.py:89-117; generated by tests/golden/make_py_fixture.py in the build container).  The
+    restatement's |.|^2 surface, viewed in that module's convention (magnitude, n lags of scipy
+    'same', reversed lag axis: out[i] = sqrt(surf[(n/2 - i) mod 2n]), caf.py:15-18,145), must
+    reproduce it: values within the reference's complex64 arithmetic, (tau, f) exactly."""
+    g = np.load(GOLDEN / "py_amb_surf.npz")
+    nd, hs = oracle.load_pair(DATA, str(g["needle"]), str(g["haystack"]))
+    fr = g["freqs"]
+    surf, _, _ = oracle.np_caf_surface(nd, hs, fr, 48000)
+    n = len(nd)
+    py = np.sqrt(surf[:, (n // 2 - np.arange(n)) % (2 * n)])
+    tol = 2e-6 * g["row_max"].max()
+    assert np.max(np.abs(py[g["full_rows"]] - g["rows"])) <= tol
+    assert np.max(np.abs(py.reshape(-1)[::int(g["stride"])] - g["strided"])) <= tol
+    fmax, tmax = np.unravel_index(py.argmax(), py.shape)
+    assert (n // 2 - tmax, fr[fmax]) == (int(g["tau"]), float(g["freq"])) == (70, 83.0)
+
+
+def test_oracles_nan_semantics(oracle, coracle):
+    """mod.rs:143-151: a NaN magnitude never satisfies `mag > max`: rows of NaN report (0, 0.0),
+    and a finite value after a NaN still wins (both restatements)."""
+    rng = np.random.default_rng(3)
+    n = 64
+    a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    b = np.roll(a, 5)
+    fr = np.array([-3.0, 0.0])
+    x = a.copy()
+    x[7] = complex(np.nan, 0.0)
+    for impl in ("np", "c"):
+        if impl == "np":
+            s, i, v = oracle.np_caf_surface(x, b, fr, 48000)
+        else:
+            s, i, v = coracle.caf_surface(x, b, fr, 48000, hoist=False, nthreads=1)
+        assert np.isnan(s).all() and not i.any() and not v.any()
+    assert oracle.np_find_peak([1.0, 2.0, 3.0], [4, 5, 6], [float("nan"), 2.0, float("nan")]) == (2.0, 5)
+    assert coracle.find_peak(np.array([1.0, 2.0, 3.0]), np.array([4, 5, 6], dtype=np.uint64),
+                             np.array([np.nan, 2.0, np.nan])) == (2.0, 5)

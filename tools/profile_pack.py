@@ -38,7 +38,8 @@ if fetch is not None and write is not None:
     # half of the bytes of 16-B-per-lane streaming reads -> doubled; WRITE_SIZE is exact for
     # 16-B-per-lane stores.
     traffic = (2.0 * fetch + write) * 1024.0
-    info = {"kernel": kernel, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "fetch_correction": 2.0,
+    info = {"kernel": kernel, "source_hash": bench.get("config", {}).get("kernel_source_hash"),
+            "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "fetch_correction": 2.0,
             "traffic_bytes_per_launch": traffic,
             "surfaces_per_launch": bench.get("config", {}).get("surfaces_per_step"),
             "dtype": bench.get("dtype"), "algorithmic_bytes_per_launch":

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Run the stamped DIAG build of the fused row kernel (internal caf_debug_set_stamps)
-and print where one Doppler row spends its shader cycles.  Diagnostic only: the
+"""Run the stamped DIAG build of the lane-half 512-thread row kernel (k_fused_rows<T, true>,
+CAF_ROW_KERNEL=1 of the measurement library) and print where one Doppler row spends its
+shader cycles.  Diagnostic only: the
 stamps serialise LDS traffic (lgkmcnt(0) at each), so read SHARES, not totals."""
 import ctypes
+import os
 import sys
 from pathlib import Path
 
@@ -20,7 +22,8 @@ NAMES = ["row start", "mixer (a prefetched)", "DFT16#1 + twA", "ex1 write", "bar
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dtype = sys.argv[2] if len(sys.argv) > 2 else "c128"
-eng = caf.Engine(0)
+os.environ["CAF_ROW_KERNEL"] = "1"  # the variant this stamp layout belongs to (read at plan creation)
+eng = caf.Engine(0, lib=caf.MEASURE_LIB_PATH)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 fr = caf.bench_shifts()
 cdt = np.complex128 if dtype == "c128" else np.complex64
@@ -33,15 +36,15 @@ ridx = torch.empty((batch, 400), dtype=torch.int64, device="cuda")
 rval = torch.empty((batch, 400), dtype=rdt, device="cuda")
 peak = torch.empty((batch, 4), dtype=torch.float64, device="cuda")
 dbg = torch.zeros((32, 8, NST), dtype=torch.int64, device="cuda")
-lib = caf.load()
-lib.caf_debug_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+lib = eng.lib
+lib.caf_debug_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
 args = (nd.data_ptr(), hs.data_ptr(), batch, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(), peak.data_ptr())
 plan.surface_dev(*args)
 torch.cuda.synchronize()
-assert lib.caf_debug_set_stamps(plan._h, ctypes.c_void_p(dbg.data_ptr())) == 0
+assert lib.caf_debug_set_stamps(plan._h, ctypes.c_void_p(dbg.data_ptr()), dbg.numel()) == 0, lib.caf_last_error_string()
 plan.surface_dev(*args)
 torch.cuda.synchronize()
-lib.caf_debug_set_stamps(plan._h, None)
+lib.caf_debug_set_stamps(plan._h, None, 0)
 d = dbg.cpu().numpy()
 iters = min(32, (batch * 400 + 255) // 256) - 1
 d = d[1:iters]  # skip the first row (cold) and the unwritten tail

@@ -15,7 +15,7 @@ NST = 28
 SEG = ["mixer(+a wait)", "DFT1+twA+ex1 W", "barrier ex1", "ex1 R+DFT2+twB+ex2 W", "ex2 R+DFT3", "H mul+DFT4+ex3 W",
        "ex3 R+twB+DFT5+ex4 W", "barrier ex4", "ex4 R+barrier", "twA+DFT6"]
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-eng = caf.Engine(0)
+eng = caf.Engine(0, lib=caf.MEASURE_LIB_PATH)  # the stamped builds exist only in the measurement library
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 fr = caf.bench_shifts()
 nd_h, hs_h, _, _ = make_batch(batch, 4096, 48000, seed0=1000)
@@ -25,17 +25,17 @@ surf = torch.empty((batch, 400, 8192), dtype=torch.float64, device="cuda")
 ridx = torch.empty((batch, 400), dtype=torch.int64, device="cuda")
 rval = torch.empty((batch, 400), dtype=torch.float64, device="cuda")
 peak = torch.empty((batch, 4), dtype=torch.float64, device="cuda")
-dbg_all = torch.zeros(32 * 4 * NST + 4 * 1024, dtype=torch.int64, device="cuda")
+dbg_all = torch.zeros(32 * 4 * NST + 4 * 8 * 256, dtype=torch.int64, device="cuda")  # stamps + 4 words per workgroup
 dbg = dbg_all[:32 * 4 * NST].view(32, 4, NST)
-lib = caf.load()
-lib.caf_debug_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+lib = eng.lib
+lib.caf_debug_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
 args = (nd.data_ptr(), hs.data_ptr(), batch, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(), peak.data_ptr())
 plan.surface_dev(*args)
 torch.cuda.synchronize()
-assert lib.caf_debug_set_stamps(plan._h, ctypes.c_void_p(dbg_all.data_ptr())) == 0
+assert lib.caf_debug_set_stamps(plan._h, ctypes.c_void_p(dbg_all.data_ptr()), dbg_all.numel()) == 0, lib.caf_last_error_string()
 plan.surface_dev(*args)
 torch.cuda.synchronize()
-rec = dbg_all[32 * 4 * NST:].view(1024, 4).cpu().numpy()[:512]
+rec = dbg_all[32 * 4 * NST:].view(-1, 4).cpu().numpy()[:512]
 t0, t1 = rec[:, 0].astype(np.float64), rec[:, 1].astype(np.float64)
 base = t0.min()
 dur = t1 - t0
@@ -78,6 +78,6 @@ def timeit(n=20):
     return a.elapsed_time(b) / n
 
 t_diag = timeit()
-lib.caf_debug_set_stamps(plan._h, None)
+lib.caf_debug_set_stamps(plan._h, None, 0)
 t_norm = timeit()
 print(f"step time: stamped build {t_diag:.4f} ms, normal build {t_norm:.4f} ms (batch {batch})")
