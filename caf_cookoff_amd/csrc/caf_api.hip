@@ -9,6 +9,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -17,6 +18,7 @@
 #include "kernels_seq4096.hpp"
 #include "kernels_duo4096.hpp"
 #include "kernels_big65536.hpp"
+#include "kernels_chain.hpp"
 #include "kernels_generic.hpp"
 // Measurement build (-DCAF_MEASURE -> libcaf_hip_measure.so, used by tools/ and the variant
 // tests only): rejected kernel variants, ablation instantiations that produce WRONG results and
@@ -96,6 +98,8 @@ struct caf_ctx {
     void *qoutw[2] = {nullptr, nullptr};    // 16x4096 path: W_L^(k1 t)
     // generic FFT twiddles per (L, dtype)
     std::map<std::pair<size_t, int>, void *> tw_cache;
+    // chain-path tables per (LOGM, R, dtype): {twM, th}
+    std::map<std::tuple<int, int, int>, std::pair<void *, void *>> chain_tabs;
     // host-API staging + cached plan
     DevBuf io_needle, io_hay, io_surface, io_ridx, io_rval, io_peak, io_a, io_b;
     caf_plan *cached = nullptr;
@@ -110,7 +114,12 @@ struct caf_plan {
     uint32_t fs = 0;
     size_t nfreq_total = 0, row_begin = 0, rows = 0;
     bool fused = false;
-    bool big = false;           // n == 32768: four-step tiled path
+    bool big = false;           // n == 32768 complex128: four-step tiled path
+    bool chain = false;         // LDS-resident chain path (kernels_chain.hpp): R chains of 2^logm points
+    int clogm = 0, cR = 0;
+    void *c_twM = nullptr, *c_th = nullptr;  // borrowed from the ctx cache
+    DevBuf slab;                             // R = 4: per-workgroup scratch of the last radix-4 stage
+    void *slab_override = nullptr;           // streaming slots bring their own
     bool bigq = false;          //   ... in its 16 x 4096 two-pass form (kernels_q65536.hpp)
     DevBuf bwork, bhwork, bpart_val, bpart_idx;
     double *d_freqs = nullptr;  // this shard's slice
@@ -238,6 +247,7 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
         if (c->qoutw[d]) (void)hipFree(c->qoutw[d]);
     }
     for (auto &kv : c->tw_cache) (void)hipFree(kv.second);
+    for (auto &kv : c->chain_tabs) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.second); }
     c->io_needle.release(); c->io_hay.release(); c->io_surface.release();
     c->io_ridx.release(); c->io_rval.release(); c->io_peak.release();
     c->io_a.release(); c->io_b.release();
@@ -355,6 +365,65 @@ extern "C" int caf_xcor_c64(caf_ctx *c, const float *a, const float *b, size_t n
     return xcor_impl<float>(c, a, b, n, out, CAF_C64);
 }
 
+// ----------------------------------------------------------- chain path set-up --
+// Which padded lengths the LDS-resident chain kernels (kernels_chain.hpp) cover: L = 2n = R * M
+// with one chain of M points (plus its padding and twiddle tables) inside 160 KiB of LDS:
+//   complex64:  M <= 16384  -> n = 1024, 2048, 8192, 16384 (R = 2), n = 32768 (R = 4, BASELINE configs[3])
+//   complex128: M <=  8192  -> n = 1024, 2048, 8192 (R = 2), n = 16384 (R = 4)
+// n = 4096 keeps its tuned kernels (kernels_seq4096.hpp / kernels_duo4096.hpp).
+static bool chain_config(size_t n, int dtype, int *logm, int *R)
+{
+    if (n < 1024 || n == (size_t)F_N || !is_pow2(n)) return false;
+    const size_t m_max = dtype == CAF_C64 ? 16384 : 8192;
+    size_t M;
+    if (n <= m_max) { M = n; *R = 2; }
+    else if (n / 2 <= m_max) { M = n / 2; *R = 4; }
+    else return false;
+    int l = 0;
+    while (((size_t)1 << l) < M) ++l;
+    *logm = l;
+    return true;
+}
+
+// CHAIN_DISPATCH(T, logm, R, STMT): run STMT with constexpr LOGM_ / R_ for the instantiated combinations
+#define CHAIN_CASE(LG, RR, STMT) if (logm_ == LG && R_rt == RR) { constexpr int LOGM_ = LG; constexpr int R_ = RR; STMT; } else
+#define CHAIN_DISPATCH(T, logm, R, STMT)                                                               \
+    do {                                                                                               \
+        const int logm_ = (logm), R_rt = (R);                                                          \
+        if constexpr (sizeof(T) == 4) {                                                                \
+            CHAIN_CASE(10, 2, STMT) CHAIN_CASE(11, 2, STMT) CHAIN_CASE(13, 2, STMT) CHAIN_CASE(14, 2, STMT) \
+            CHAIN_CASE(14, 4, STMT) return fail(CAF_ERR_STATE, "chain path: no kernel for M=2^%d R=%d", logm_, R_rt); \
+        } else {                                                                                       \
+            CHAIN_CASE(10, 2, STMT) CHAIN_CASE(11, 2, STMT) CHAIN_CASE(13, 2, STMT) CHAIN_CASE(13, 4, STMT) \
+            return fail(CAF_ERR_STATE, "chain path: no kernel for M=2^%d R=%d", logm_, R_rt);           \
+        }                                                                                              \
+    } while (0)
+
+template <typename T>
+static int build_chain_tables(caf_plan *p)
+{
+    caf_ctx *c = p->ctx;
+    const int M = 1 << p->clogm, R = p->cR, W = M / 16;
+    auto key = std::make_tuple(p->clogm, R, p->dtype);
+    auto it = c->chain_tabs.find(key);
+    if (it == c->chain_tabs.end()) {
+        void *twM = nullptr, *th = nullptr;
+        HIPCHK(hipMalloc(&twM, (size_t)M * sizeof(cpx<T>)));
+        HIPCHK(hipMalloc(&th, (size_t)(R - 1) * W * sizeof(cpx<T>)));
+        k_chain_tables<T><<<(unsigned)((M + 255) / 256), 256, 0, c->stream>>>((cpx<T> *)twM, (cpx<T> *)th, M, R);
+        KCHK();
+        it = c->chain_tabs.emplace(key, std::make_pair(twM, th)).first;
+    }
+    p->c_twM = it->second.first;
+    p->c_th = it->second.second;
+    const size_t nr = p->rows + 1;  // +1: the f = 0 row for the haystack transform
+    HIPCHK(hipMalloc(&p->d_phasor, nr * CH_PH * sizeof(cpx<T>)));
+    k_chain_phasors<T><<<(unsigned)((nr * CH_PH + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows, M, R,
+                                                                                 (cpx<T> *)p->d_phasor);
+    KCHK();
+    return CAF_OK;
+}
+
 // -------------------------------------------------------------------- plan --
 template <typename T>
 static int plan_build_tables(caf_plan *p)
@@ -378,6 +447,7 @@ static int plan_build_tables(caf_plan *p)
         return CAF_OK;
     }
 #endif
+    if (p->chain) return build_chain_tables<T>(p);
     if (p->big) {
         if (!c->bigw256[dt]) {
             HIPCHK(hipMalloc(&c->bigw256[dt], 256 * sizeof(cpx<T>)));
@@ -434,7 +504,9 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     p->row_begin = row_begin;
     p->rows = row_end - row_begin;
     p->fused = (n == (size_t)F_N);
-    p->big = (n == (size_t)B_N);
+    // (CAF_CHAIN=0, measurement build: keep the older tiled65536 / generic paths reachable for comparison)
+    p->chain = measure_env("CAF_CHAIN", 1) != 0 && chain_config(n, dtype, &p->clogm, &p->cR);
+    p->big = !p->chain && (n == (size_t)B_N);
     p->variant = dtype == CAF_C64 ? 3 : 0;  // f32: two chains in flight; f64: sequential chains (kernels_duo4096.hpp)
     // measurement build only: CAF_BIG_PATH=1 = the 16 x 4096 two-pass form (parity-green, 2.63 vs 2.19 ms per
     // 4096-row surface); CAF_ROW_KERNEL = 0..3 picks the n = 4096 row kernel.  No-ops in the product library.
@@ -484,6 +556,7 @@ extern "C" int caf_plan_destroy(caf_plan *p)
     if (p->d_phasor) (void)hipFree(p->d_phasor);
     p->spec.release(); p->wx.release(); p->wy.release(); p->hx.release(); p->hy.release();
     p->bwork.release(); p->bhwork.release(); p->bpart_val.release(); p->bpart_idx.release();
+    p->slab.release();
     for (auto ev : p->ev) (void)hipEventDestroy(ev);
     if (p->ctx->cached == p) p->ctx->cached = nullptr;
     delete p;
@@ -492,13 +565,18 @@ extern "C" int caf_plan_destroy(caf_plan *p)
 
 extern "C" const char *caf_plan_path(const caf_plan *p)
 {
-    return !p ? "" : p->fused ? "fused4096" : p->big ? "tiled65536" : "generic";
+    return !p ? "" : p->fused ? "fused4096" : p->chain ? "chain" : p->big ? "tiled65536" : "generic";
 }
 extern "C" size_t caf_plan_rows(const caf_plan *p) { return p ? p->rows : 0; }
 extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
 {
     if (!p) return "";
     const bool f64 = p->dtype == CAF_C128;
+    if (p->chain) {
+        static thread_local char name[64];
+        snprintf(name, sizeof name, "caf::k_chain_rows<%s, %d, %d>", f64 ? "double" : "float", p->clogm, p->cR);
+        return name;
+    }
     if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";  // measurement build
     if (p->big) return f64 ? "caf::k_big_rows<double>" : "caf::k_big_rows<float>";
     if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
@@ -736,6 +814,52 @@ static int surface_dev_q(caf_plan *p, const void *d_needle, const void *d_hay, s
 }
 #endif  // CAF_MEASURE
 
+// LDS-resident chain path (kernels_chain.hpp)
+template <typename T>
+static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
+                             uint64_t *d_ridx, void *d_rval)
+{
+    caf_ctx *c = p->ctx;
+    const int R = p->cR, M = 1 << p->clogm, W = M / 16;
+    const size_t total = batch * p->rows;
+    int rc;
+    if (!p->spec_override && (rc = p->spec.ensure(batch * (size_t)R * M * sizeof(cpx<T>)))) return rc;
+    ChainArgs<T> a;
+    a.twM = (const cpx<T> *)p->c_twM;
+    a.th = (const cpx<T> *)p->c_th;
+    a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
+    a.rows = (int)p->rows;
+    a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr; a.slab = nullptr;
+    const cpx<T> *phasor = (const cpx<T> *)p->d_phasor;
+    const size_t cap = (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, sizeof(cpx<T>));
+    // haystack spectrum, once per surface (the reference recomputes it per row, xcor_rustfft.rs:58-59)
+    a.sig = (const cpx<T> *)d_hay;
+    a.total = (int)batch;
+    {
+        const size_t want = (size_t)R * batch;
+        const unsigned grid = (unsigned)(want < cap ? want : cap);
+        CHAIN_DISPATCH(T, p->clogm, R, (k_chain_prepare<T, LOGM_, R_><<<grid, W, 0, c->stream>>>(a, phasor)));
+    }
+    KCHK();
+    if (total == 0) return CAF_OK;
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
+    if (R == 4) {
+        const size_t slab_bytes = (size_t)cap * 2 * 16 * W * sizeof(cpx<T>);
+        if (!p->slab_override && (rc = p->slab.ensure(slab_bytes))) return rc;
+        a.slab = (cpx<T> *)(p->slab_override ? p->slab_override : p->slab.p);
+    }
+    a.sig = (const cpx<T> *)d_needle;
+    a.total = (int)total;
+    a.surface = (T *)d_surface;
+    a.row_idx = d_ridx;
+    a.row_val = (T *)d_rval;
+    if ((rc = timing_mark(p))) return rc;
+    CHAIN_DISPATCH(T, p->clogm, R, (k_chain_rows<T, LOGM_, R_><<<grid, W, 0, c->stream>>>(a, phasor)));
+    KCHK();
+    if ((rc = timing_mark(p))) return rc;
+    return CAF_OK;
+}
+
 // n = 32768: four-step tiled path (kernels_big65536.hpp)
 template <typename T>
 static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
@@ -867,6 +991,7 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
     int rc;
     if (p->dtype == CAF_C128)
         rc = p->fused ? surface_dev_fused<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+             : p->chain ? surface_dev_chain<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
 #ifdef CAF_MEASURE
              : p->big && p->bigq ? surface_dev_q<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
 #endif
@@ -874,6 +999,7 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
                       : surface_dev_generic<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     else
         rc = p->fused ? surface_dev_fused<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+             : p->chain ? surface_dev_chain<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
 #ifdef CAF_MEASURE
              : p->big && p->bigq ? surface_dev_q<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
 #endif
@@ -1028,7 +1154,8 @@ struct StreamSlot {
     void *h_peak = nullptr, *h_ridx = nullptr, *h_rval = nullptr;  // pinned results
     void *d_needle = nullptr, *d_hay = nullptr, *d_surface = nullptr;
     void *d_ridx = nullptr, *d_rval = nullptr, *d_peak = nullptr;
-    void *d_spec = nullptr;  // fused plans: this slot's haystack spectra
+    void *d_spec = nullptr;  // fused / chain plans: this slot's haystack spectra
+    void *d_slab = nullptr;  // chain plans with R = 4: this slot's radix-4 scratch
     bool own_stream = true;
 };
 
@@ -1048,7 +1175,7 @@ static void stream_free(caf_stream *st)
         if (s.graph) (void)hipGraphDestroy(s.graph);
         for (void *p : {s.h_needle, s.h_hay, s.h_peak, s.h_ridx, s.h_rval})
             if (p) (void)hipHostFree(p);
-        for (void *p : {s.d_needle, s.d_hay, s.d_surface, s.d_ridx, s.d_rval, s.d_peak, s.d_spec})
+        for (void *p : {s.d_needle, s.d_hay, s.d_surface, s.d_ridx, s.d_rval, s.d_peak, s.d_spec, s.d_slab})
             if (p) (void)hipFree(p);
         if (s.stream && s.own_stream) (void)hipStreamDestroy(s.stream);
     }
@@ -1074,7 +1201,7 @@ extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want
     const size_t surf_bytes = batch * rows * p->L * real_size(p->dtype);
     hipStream_t saved = c->stream;
     int rc = CAF_OK;
-    auto bail = [&](int code) { c->stream = saved; p->spec_override = nullptr; stream_free(st); return code; };
+    auto bail = [&](int code) { c->stream = saved; p->spec_override = nullptr; p->slab_override = nullptr; stream_free(st); return code; };
 #define SCHK(expr)                                                                                         \
     do {                                                                                                   \
         hipError_t e__ = (expr);                                                                           \
@@ -1082,15 +1209,21 @@ extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want
     } while (0)
     for (size_t si = 0; si < st->slots.size(); ++si) {
         StreamSlot &s = st->slots[si];
-        // Fused plans: every slot has private device state -> slots run concurrently on their
-        // own streams.  Generic-path plans share the plan's pass workspaces -> one stream.
-        if (p->fused || si == 0) {
+        // Fused / chain plans: every slot has private device state -> slots run concurrently on
+        // their own streams.  tiled65536 / generic plans share the plan's pass workspaces -> one stream.
+        if (p->fused || p->chain || si == 0) {
             SCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         } else {
             s.stream = st->slots[0].stream;
             s.own_stream = false;
         }
         if (p->fused) SCHK(hipMalloc(&s.d_spec, batch * 2 * 16 * 256 * elem_size(p->dtype) + 256));
+        if (p->chain) {
+            SCHK(hipMalloc(&s.d_spec, batch * p->L * elem_size(p->dtype)));
+            if (p->cR == 4)
+                SCHK(hipMalloc(&s.d_slab, (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, elem_size(p->dtype)) * 2 * 16 *
+                                              ((size_t)1 << p->clogm) / 16 * elem_size(p->dtype)));
+        }
         SCHK(hipHostMalloc(&s.h_needle, in_bytes, hipHostMallocDefault));
         SCHK(hipHostMalloc(&s.h_hay, in_bytes, hipHostMallocDefault));
         SCHK(hipHostMalloc(&s.h_peak, batch * sizeof(caf_peak), hipHostMallocDefault));
@@ -1121,6 +1254,7 @@ extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want
     for (auto &s : st->slots) {
         c->stream = s.stream;
         p->spec_override = s.d_spec;
+        p->slab_override = s.d_slab;
         SCHK(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
         hipError_t e1 = hipMemcpyAsync(s.d_needle, s.h_needle, in_bytes, hipMemcpyHostToDevice, s.stream);
         hipError_t e2 = hipMemcpyAsync(s.d_hay, s.h_hay, in_bytes, hipMemcpyHostToDevice, s.stream);
@@ -1130,6 +1264,7 @@ extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want
         hipError_t e5 = p->rows ? hipMemcpyAsync(s.h_rval, s.d_rval, rval_bytes, hipMemcpyDeviceToHost, s.stream) : hipSuccess;
         hipError_t ec = hipStreamEndCapture(s.stream, &s.graph);
         p->spec_override = nullptr;
+        p->slab_override = nullptr;
         p->timing = was_timing;
         if (rc) return bail(rc);
         for (hipError_t e : {e1, e2, e3, e4, e5, ec})

@@ -117,7 +117,7 @@ def test_fused_vs_generic_path_agree(eng, oracle):
 
 
 # ------------------------------------------------------------- generic path --
-@pytest.mark.parametrize("n", [1, 2, 8, 64, 512, 2048, 8192])
+@pytest.mark.parametrize("n", [1, 2, 8, 64, 512, 1024, 2048, 8192, 16384])
 def test_generic_sizes_vs_oracle(n, eng, oracle):
     rng = np.random.default_rng(n)
     a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
@@ -507,17 +507,17 @@ def test_streaming_double_buffer(eng, oracle, golden, manifest):
 
 
 # ------------------------------------------------------------ configs[3] shape --
-def test_L65536_c64_tiled_path_rows(eng, oracle):
+def test_L65536_c64_rows(eng, oracle):
     """BASELINE configs[3] geometry (n = 32768 -> L = 65536, complex64) on a few Doppler
-    rows: the four-step tiled path against the f64 oracle, tolerance 1e-3 of max, and the
-    synthetic pair's known (lag, Doppler) recovered."""
+    rows: the chain path (4 chains of 16384 points) against the f64 oracle, tolerance 1e-3 of
+    max, and the synthetic pair's known (lag, Doppler) recovered."""
     import caf_cookoff_amd as caf
     from caf_cookoff_amd.synth import make_pair
     n = 32768
     s0, s1, lag, fo = make_pair(n=n, seed=77, lag=173, foffset=12.0, dtype=np.complex64)
     fr = np.array([11.0, 11.5, 12.0, 12.5, 13.0])
     plan = eng.plan(n, fr, FS, dtype="c64")
-    assert plan.path == "tiled65536"
+    assert plan.path == "chain" and plan.kernel_name == "caf::k_chain_rows<float, 14, 4>"
     plan.close()
     surf, ridx, rval, peak = eng.surface_arrays(s0, s1, fr, FS, dtype="c64")
     osurf, oidx, oval = oracle.np_caf_surface(s0.astype(np.complex128), s1.astype(np.complex128), fr, FS)
@@ -565,6 +565,7 @@ def test_L65536_two_pass_variant(meng, oracle, monkeypatch):
     from caf_cookoff_amd.synth import make_pair
     eng = meng
     monkeypatch.setenv("CAF_BIG_PATH", "1")
+    monkeypatch.setenv("CAF_CHAIN", "0")
     n = 32768
     fr = np.array([11.5, 12.0, 12.5, -3.0])
     for dtype, cdt, tol in (("c64", np.complex64, TOL32), ("c128", np.complex128, TOL64)):
@@ -597,10 +598,27 @@ def _plan_arrays_n(plan, eng, nd, hs, dtype, n):
     return surf[0].cpu().numpy().astype(np.float64), ridx[0].cpu().numpy(), rval[0].cpu().numpy(), pk
 
 
-def test_generic_path_still_covers_other_big_sizes(eng, oracle):
-    """n = 16384 (L = 32768) has no fused kernel: generic HBM-pass path."""
+def test_tiled65536_c64_via_measurement_build(meng, oracle, monkeypatch):
+    """The four-step tiled path in complex64 (the product's n = 32768 complex64 plans moved to the
+    chain path in round 2; complex128 still uses it): reachable through the measurement library
+    with CAF_CHAIN=0, and still parity-green."""
     from caf_cookoff_amd.synth import make_pair
-    n = 16384
+    monkeypatch.setenv("CAF_CHAIN", "0")
+    n = 32768
+    s0, s1, lag, fo = make_pair(n=n, seed=77, lag=173, foffset=12.0, dtype=np.complex64)
+    fr = np.array([11.5, 12.0, 12.5])
+    plan = meng.plan(n, fr, FS, dtype="c64")
+    assert plan.path == "tiled65536"
+    surf, ridx, rval, pk = _plan_arrays_n(plan, meng, s0, s1, "c64", n)
+    plan.close()
+    osurf, oidx, oval = oracle.np_caf_surface(s0.astype(np.complex128), s1.astype(np.complex128), fr, FS)
+    assert np.max(np.abs(surf - osurf)) <= TOL32 * osurf.max() and (pk["freq"], int(pk["idx"])) == (12.0, lag)
+
+
+def test_generic_path_still_covers_other_big_sizes(eng, oracle):
+    """n = 65536 (L = 131072) exceeds every LDS-resident form: generic HBM-pass path."""
+    from caf_cookoff_amd.synth import make_pair
+    n = 65536
     s0, s1, lag, fo = make_pair(n=n, seed=79, lag=33, foffset=5.0)
     fr = np.array([4.5, 5.0, 5.5])
     plan = eng.plan(n, fr, FS)

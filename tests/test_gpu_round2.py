@@ -248,3 +248,98 @@ def test_lifetime_rules(eng):
     p2 = e2.plan(64, fr, FS)
     e2.close()
     assert p2._h is None
+
+
+# ------------------------------------------ (7) LDS-resident chain path, every covered n --
+CHAIN_CASES = [(1024, "c128", "caf::k_chain_rows<double, 10, 2>"), (2048, "c128", "caf::k_chain_rows<double, 11, 2>"),
+               (8192, "c128", "caf::k_chain_rows<double, 13, 2>"), (16384, "c128", "caf::k_chain_rows<double, 13, 4>"),
+               (1024, "c64", "caf::k_chain_rows<float, 10, 2>"), (2048, "c64", "caf::k_chain_rows<float, 11, 2>"),
+               (8192, "c64", "caf::k_chain_rows<float, 13, 2>"), (16384, "c64", "caf::k_chain_rows<float, 14, 2>"),
+               (32768, "c64", "caf::k_chain_rows<float, 14, 4>")]
+
+
+@pytest.mark.parametrize("n,dtype,kernel", CHAIN_CASES, ids=lambda v: str(v) if not isinstance(v, str) or len(v) < 6 else None)
+def test_chain_path_vs_oracle(n, dtype, kernel, eng, oracle):
+    """Every power-of-two n the LDS-resident chain kernels cover (kernels_chain.hpp; "any power
+    of two" used to mean log2(L) radix-2 passes over HBM): whole surfaces against the numpy
+    restatement of mod.rs:121-166, 1e-6 / 1e-3 of max, row argmax equal wherever the oracle's row
+    has a clear winner, planted (lag, Doppler) recovered, negative lag (index >= n), a batch of
+    two pairs and a row shard through the device API."""
+    import torch
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.synth import make_pair
+    cdt = np.complex128 if dtype == "c128" else np.complex64
+    tol = TOL64 if dtype == "c128" else TOL32
+    lag = 7 + n // 37
+    s0, s1, _, fo = make_pair(n=n, seed=n + (dtype == "c64"), lag=lag, foffset=-31.5, dtype=cdt)
+    fr = np.array([-40.0, -32.0, -31.5, -31.0, 0.0, 31.5, 977.25])
+    plan = eng.plan(n, fr, FS, dtype=dtype)
+    assert plan.path == "chain" and plan.kernel_name == kernel
+    plan.close()
+    surf, ridx, rval, peak = eng.surface_arrays(s0, s1, fr, FS, dtype=dtype)
+    osurf, oidx, oval = oracle.np_caf_surface(s0.astype(np.complex128), s1.astype(np.complex128), fr, FS)
+    err = np.max(np.abs(surf - osurf)) / osurf.max()
+    print(f"chain n={n} {dtype}: max|d|/max = {err:.3e}")
+    assert err <= tol
+    part = np.partition(osurf, -2, axis=1)
+    clear = (part[:, -1] - part[:, -2]) > (1e-9 if dtype == "c128" else 1e-4) * osurf.max()
+    assert clear.any() and np.array_equal(ridx[clear], oidx[clear])
+    assert (peak.freq, int(peak.idx)) == oracle.np_find_peak(fr, oidx, oval) == (-31.5, lag)
+    assert np.array_equal(surf.argmax(axis=1).astype(np.uint64)[clear], ridx[clear])
+    assert np.array_equal(surf.max(axis=1), rval)
+    # swapped roles: negative lag -> index 2n - lag, Doppler changes sign
+    s2, i2, v2, p2 = eng.surface_arrays(s1, s0, fr, FS, dtype=dtype)
+    assert (p2.freq, int(p2.idx)) == (31.5, 2 * n - lag)
+    # device API: batch of two pairs x row shard [2, 6)
+    tdt = torch.float64 if dtype == "c128" else torch.float32
+    nd = torch.from_numpy(np.stack([s0, s1])).cuda()
+    hs = torch.from_numpy(np.stack([s1, s0])).cuda()
+    shard = eng.plan(n, fr, FS, dtype=dtype, row_begin=2, row_end=6)
+    d_s = torch.empty((2, 4, 2 * n), dtype=tdt, device="cuda")
+    d_i = torch.empty((2, 4), dtype=torch.int64, device="cuda")
+    d_v = torch.empty((2, 4), dtype=tdt, device="cuda")
+    d_p = torch.empty((2, 4), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    shard.surface_dev(nd.data_ptr(), hs.data_ptr(), 2, d_s.data_ptr(), d_i.data_ptr(), d_v.data_ptr(), d_p.data_ptr())
+    eng.synchronize()
+    shard.close()
+    assert np.array_equal(d_s[0].cpu().numpy(), surf[2:6]) and np.array_equal(d_s[1].cpu().numpy(), s2[2:6])
+    assert np.array_equal(d_i[0].cpu().numpy().astype(np.uint64), ridx[2:6])
+    pk = d_p.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[:, 0]
+    assert (int(pk[0]["row"]), int(pk[0]["idx"])) == (2, lag) and (int(pk[1]["row"]), int(pk[1]["idx"])) == (5, 2 * n - lag)
+    # all-zero input and a NaN sample (mod.rs:143-151)
+    z = np.zeros(n, dtype=cdt)
+    sz, iz, vz, pz = eng.surface_arrays(z, z, fr[:2], FS, dtype=dtype)
+    assert not sz.any() and (pz.freq, pz.idx, pz.row) == (0.0, 0, -1)
+    bad = s0.copy()
+    bad[n // 2 + 3] = complex(np.nan, 0.0)
+    sn, i_n, vn, pn = eng.surface_arrays(bad, s1, fr[:2], FS, dtype=dtype)
+    assert np.isnan(sn).all() and not i_n.any() and (pn.freq, pn.idx, pn.row) == (0.0, 0, -1)
+
+
+def test_chain_streaming_slots(eng, oracle):
+    """Streaming through a chain plan: every slot owns its spectrum (and radix-4 scratch) buffers, so
+    two slots in flight do not disturb each other (n = 32768 complex64, R = 4)."""
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.synth import make_pair
+    n = 32768
+    fr = np.array([-5.0, 0.0, 5.0, 10.0])
+    pairs = [make_pair(n=n, seed=500 + k, lag=20 + 11 * k, foffset=[5.0, -5.0, 10.0, 0.0][k], dtype=np.complex64) for k in range(4)]
+    plan = eng.plan(n, fr, FS, dtype="c64")
+    st = caf.Stream(plan, batch=1, nslots=2, want_surface=True)
+    try:
+        got = {}
+        for rnd in range(2):
+            for slot in range(2):
+                k = 2 * rnd + slot
+                a, b = st.buffers(slot)
+                a[0], b[0] = pairs[k][0], pairs[k][1]
+                st.submit(slot)
+            for slot in range(2):
+                peaks, _, _ = st.wait(slot, want_rows=False)
+                got[2 * rnd + slot] = (float(peaks[0]["freq"]), int(peaks[0]["idx"]))
+        for k in range(4):
+            assert got[k] == (pairs[k][3], pairs[k][2]), f"pair {k}"
+    finally:
+        st.close()
+        plan.close()
