@@ -117,20 +117,33 @@ __device__ __forceinline__ cpx<float> cmul_conj(cpx<float> a, cpx<float> b)
         : "=v"(r) : "v"(av), "v"(bv), "v"(t));
     return unpk(r);
 }
-// v + r (i v)  and  r v + i v  (the Linzer-Feig pre-rotations of bfly_w)
+// v + r (i v)  and  r v + i v  (the Linzer-Feig pre-rotations of bfly_w).  r is a compile-time
+// constant after inlining: it is passed in an SGPR pair ("s"), not a VGPR pair -- a kernel's
+// butterfly constants (dozens of distinct ones) then cost scalar registers and s_mov, not vector
+// registers the row data needs (the chain kernels run at 128 VGPRs).
 __device__ __forceinline__ cpx<float> lf_tan(cpx<float> v, float r)
 {
     caf_v2f o;
     asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]"
-        : "=v"(o) : "v"(caf_v2f{r, r}), "v"(pk(v)));
+        : "=v"(o) : "s"(caf_v2f{r, r}), "v"(pk(v)));
     return unpk(o);
 }
 __device__ __forceinline__ cpx<float> lf_cot(cpx<float> v, float r)
 {
     caf_v2f o;
     asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[0,1,0] neg_lo:[0,0,1]"
-        : "=v"(o) : "v"(caf_v2f{r, r}), "v"(pk(v)));
+        : "=v"(o) : "s"(caf_v2f{r, r}), "v"(pk(v)));
     return unpk(o);
+}
+// u + g b and u - g b for a compile-time real g (SGPR operand, low half broadcast to both lanes)
+__device__ __forceinline__ void axpy_pm_const(float g, cpx<float> b, cpx<float> u, cpx<float> &p, cpx<float> &m)
+{
+    caf_v2f pp, mm;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(pp) : "s"(caf_v2f{g, g}), "v"(pk(b)), "v"(pk(u)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+        : "=v"(mm) : "s"(caf_v2f{g, g}), "v"(pk(b)), "v"(pk(u)));
+    p = unpk(pp);
+    m = unpk(mm);
 }
 
 __device__ __forceinline__ double vfma(double a, double b, double c) { return __builtin_fma(a, b, c); }

@@ -345,7 +345,11 @@ __device__ __forceinline__ cpx<T> chain_pb(const cpx<T> *__restrict__ ph, int t)
     return pb;
 }
 
-// chain input: v[q] = conj(x[q] * step_r[q]),  x = a0 (R = 2) or a0 + (-i)^r wM a1 (R = 4)
+// chain input: v[q] = conj(x[q] * step_r[q]),  x = a0 (R = 2) or a0 + (-i)^r wM a1 (R = 4).
+// The samples are fetched in groups of four register rows, one group ahead of its use: at most
+// 2 x 4 (R = 2) / 2 x 8 (R = 4) loads are in flight.  Hoisting all 16 / 32 of them (what the
+// scheduler does on its own) costs 32 / 64 VGPRs on top of the 64 the two chains' data need and
+// spills at four waves per SIMD.
 template <typename T, int LOGM, int R>
 __device__ __forceinline__ void chain_input(cpx<T> (&v)[16], const __amdgpu_buffer_rsrc_t rs_sig, int r, int t,
                                             const cpx<T> *__restrict__ ph)
@@ -354,22 +358,32 @@ __device__ __forceinline__ void chain_input(cpx<T> (&v)[16], const __amdgpu_buff
     constexpr int W = ChainGeo<LOGM>::W, M = ChainGeo<LOGM>::M;
     const C *ps = ph + 48 + 16 * r;
     const unsigned voff = (unsigned)(t * sizeof(C));
-    if constexpr (R == 2) {
+    C wM = C{T(1), T(0)};
+    if constexpr (R == 4) wM = ph[112];
+    C a0[2][4], a1[2][4];
+    auto fetch = [&](int grp) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const C a0 = bload(rs_sig, voff, (unsigned)(W * q * sizeof(C)), (C *)nullptr);
-            v[q] = cmul_conj(a0, ps[q]);
+        for (int u = 0; u < 4; ++u) {
+            const int q = 4 * grp + u;
+            a0[grp & 1][u] = bload(rs_sig, voff, (unsigned)(W * q * sizeof(C)), (C *)nullptr);
+            if constexpr (R == 4) a1[grp & 1][u] = bload(rs_sig, voff, (unsigned)((M + W * q) * sizeof(C)), (C *)nullptr);
         }
-    } else {
-        const C wM = ph[112];
+    };
+    fetch(0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const C a0 = bload(rs_sig, voff, (unsigned)(W * q * sizeof(C)), (C *)nullptr);
-            const C a1 = bload(rs_sig, voff, (unsigned)((M + W * q) * sizeof(C)), (C *)nullptr);
-            const C b = cmul(a1, wM);
-            const C x = r == 0 ? a0 + b : r == 1 ? sub_i(a0, b) : r == 2 ? a0 - b : add_i(a0, b);
+    for (int grp = 0; grp < 4; ++grp) {
+        if (grp < 3) fetch(grp + 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = 4 * grp + u;
+            C x = a0[grp & 1][u];
+            if constexpr (R == 4) {
+                const C b = cmul(a1[grp & 1][u], wM);
+                x = r == 0 ? x + b : r == 1 ? sub_i(x, b) : r == 2 ? x - b : add_i(x, b);
+            }
             v[q] = cmul_conj(x, ps[q]);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -407,7 +421,7 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W) void k_chain_prepare(const Chain
     const T inv = T(1.0 / (double)(R * G::M));
     __syncthreads();
     for (int w = blockIdx.x; w < R * A.total; w += gridDim.x) {
-        const int b = w / R, r = w % R;
+        const int b = __builtin_amdgcn_readfirstlane(w / R), r = __builtin_amdgcn_readfirstlane(w % R);
         const __amdgpu_buffer_rsrc_t rs_sig = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.sig + (size_t)b * NS_IN), 0, NS_IN * (int)sizeof(C), 0x00020000);
         C lane = chain_pb<T, LOGM>(ph, L.t);
@@ -440,8 +454,14 @@ __device__ __forceinline__ void chain_run(cpx<T> (&v)[16], const ChainLane<T, LO
     L.forward(v, conj(lane));
     const unsigned voff = (unsigned)((r * 16 * G::W + L.t) * sizeof(C));
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-        v[k] = cmul(v[k], bload(rs_spec, voff, (unsigned)(G::W * k * sizeof(C)), (C *)nullptr));  // xcor_rustfft.rs:64-73
+    for (int half = 0; half < 2; ++half) {  // two groups of eight loads (register pressure, see chain_input)
+        C h[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = bload(rs_spec, voff, (unsigned)(G::W * (8 * half + k) * sizeof(C)), (C *)nullptr);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[8 * half + k] = cmul(v[8 * half + k], h[k]);  // xcor_rustfft.rs:64-73
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (r) {
         const TwFold<T> fpost(L.tw, post);
         L.inverse(v, [&](int k, C x) { return twA_k(x, k, L.tw, fpost); });
@@ -468,7 +488,10 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W, chain_wps_v(LOGM, sizeof(cpx<T>)
     __syncthreads();
 
     for (int g = blockIdx.x; g < A.total; g += gridDim.x) {
-        const int b = g / A.rows, r_row = g - b * A.rows;
+        // g is workgroup-uniform; the division runs on the VALU, so pin the results to SGPRs (a buffer
+        // descriptor built from a VGPR value costs a waterfall loop per load)
+        const int b = __builtin_amdgcn_readfirstlane(g / A.rows);
+        const int r_row = __builtin_amdgcn_readfirstlane(g - b * A.rows);
         const C *__restrict__ ph = phasor + (size_t)r_row * CH_PH;
         const __amdgpu_buffer_rsrc_t rs_sig = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.sig + (size_t)b * NS_IN), 0, NS_IN * (int)sizeof(C), 0x00020000);
@@ -505,7 +528,11 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W, chain_wps_v(LOGM, sizeof(cpx<T>)
                 emit(1, i, hi);
             }
         } else {
-            C *const slab = A.slab + (size_t)blockIdx.x * (2 * 16 * W) + L.t;
+            // this workgroup's scratch slab through a buffer descriptor: per-lane byte offset in one VGPR,
+            // the register-row offset in an SGPR (32 separate 64-bit global addresses would cost 64 VGPRs)
+            const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(A.slab + (size_t)blockIdx.x * (2 * 16 * W)), 0, 2 * 16 * W * (int)sizeof(C), 0x00020000);
+            const unsigned voff_slab = (unsigned)(L.t * sizeof(C));
             {
                 C y0[16], y2[16];
                 chain_run<T, LOGM, R>(y0, L, A, rs_sig, rs_spec, 0, pb, ph);
@@ -514,8 +541,8 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W, chain_wps_v(LOGM, sizeof(cpx<T>)
                 for (int i = 0; i < 16; ++i) {  // a, b = y0 +- W_64^(2 i) y2'
                     C a, bb;
                     bfly_w(y0[i], y2[i], W64C[2 * i], W64S[2 * i], a, bb);
-                    slab[(size_t)i * W] = a;
-                    slab[(size_t)(16 + i) * W] = bb;
+                    bstore(rs_slab, voff_slab, (unsigned)(i * W * sizeof(C)), a);
+                    bstore(rs_slab, voff_slab, (unsigned)((16 + i) * W * sizeof(C)), bb);
                 }
             }
             C y1[16], y3[16];
@@ -526,7 +553,8 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W, chain_wps_v(LOGM, sizeof(cpx<T>)
                 // c' , d' = y1' +- W_64^(3i - i) y3' = y1' +- W_64^(2i) y3'   (z_r = W_64^(i r) y'_r)
                 C cc, dd;
                 bfly_w(y1[i], y3[i], W64C[2 * i], W64S[2 * i], cc, dd);
-                const C a = slab[(size_t)i * W], bb = slab[(size_t)(16 + i) * W];
+                const C a = bload(rs_slab, voff_slab, (unsigned)(i * W * sizeof(C)), (C *)nullptr);
+                const C bb = bload(rs_slab, voff_slab, (unsigned)((16 + i) * W * sizeof(C)), (C *)nullptr);
                 C c0, c2, c1, c3;
                 bfly_w(a, cc, W64C[i], W64S[i], c0, c2);              // a +- W_64^i c'
                 bfly_w(bb, dd, -W64S[i], W64C[i], c1, c3);           // b +- i W_64^i d'
@@ -534,6 +562,7 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W, chain_wps_v(LOGM, sizeof(cpx<T>)
                 emit(1, i, c1);
                 emit(2, i, c2);
                 emit(3, i, c3);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four (a, b) pairs in flight
             }
         }
         // lags of block j all precede those of block j+1: init (0.0, lag 0) like mod.rs:143

@@ -119,9 +119,7 @@ __device__ __forceinline__ void axpy_pm(T g, cpx<T> b, cpx<T> u, cpx<T> &p, cpx<
 }
 __device__ __forceinline__ void axpy_pm(float g, cpx<float> b, cpx<float> u, cpx<float> &p, cpx<float> &m)
 {
-    const caf_v2f gg = {g, g}, bv = pk(b), uv = pk(u);
-    p = unpk(__builtin_elementwise_fma(gg, bv, uv));
-    m = unpk(__builtin_elementwise_fma(-gg, bv, uv));
+    axpy_pm_const(g, b, u, p, m);  // g is a compile-time constant at every call site: SGPR operand (cplx.hpp)
 }
 
 // p = u + w v, m = u - w v for a unit constant w = c + i s known at compile time (after
@@ -581,6 +579,18 @@ __device__ __forceinline__ cpx<float> bload(__amdgpu_buffer_rsrc_t rs, unsigned 
 {
     const caf_v2u r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
     return {__uint_as_float(r.x), __uint_as_float(r.y)};
+}
+
+// complex store through a buffer descriptor (default cache policy), twin of bload
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, cpx<double> x)
+{
+    const long long a = __double_as_longlong(x.x), b = __double_as_longlong(x.y);
+    __builtin_amdgcn_raw_buffer_store_b128(caf_v4u{(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)}, rs,
+                                           voff, soff, 0);
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, cpx<float> x)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(caf_v2u{__float_as_uint(x.x), __float_as_uint(x.y)}, rs, voff, soff, 0);
 }
 
 // ---- the row kernel ------------------------------------------------------------------------
