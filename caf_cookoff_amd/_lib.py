@@ -27,6 +27,7 @@ CAF_C128 = 0
 CAF_C64 = 1
 CAF_VIEW_GO = 1
 CAF_VIEW_PYTHON = 2
+CAF_STREAM_SPLIT = 1
 
 
 class CafPeak(ctypes.Structure):
@@ -77,6 +78,7 @@ SYMBOLS = [
     ("caf_plan_timing_end", _int, [_vp, _dp, _up]),
     ("caf_surface_view", _int, [_vp, _int, _vp, _sz, _sz, _int, _vp]),
     ("caf_stream_create", _int, [_vp, _sz, _int, _int, ctypes.POINTER(_vp)]),
+    ("caf_stream_create_ex", _int, [_vp, _sz, _int, _int, ctypes.c_uint, ctypes.POINTER(_vp)]),
     ("caf_stream_destroy", _int, [_vp]),
     ("caf_stream_host_buffers", _int, [_vp, _int, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     ("caf_stream_submit", _int, [_vp, _int]),

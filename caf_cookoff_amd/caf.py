@@ -286,11 +286,13 @@ class Stream:
 
     PEAK_DTYPE = np.dtype([("val", "<f8"), ("freq", "<f8"), ("idx", "<u8"), ("row", "<i8")])
 
-    def __init__(self, plan: "Plan", batch: int, nslots: int = 2, want_surface: bool = True):
+    def __init__(self, plan: "Plan", batch: int, nslots: int = 2, want_surface: bool = True, split: bool = False):
+        """``split``: the slot's graph holds ``batch`` independent single-surface node chains
+        (CAF_STREAM_SPLIT) instead of one batched chain."""
         self.plan, self.batch, self.nslots = plan, int(batch), int(nslots)
         h = ctypes.c_void_p()
-        plan.eng._check(plan.eng.lib.caf_stream_create(plan._h, self.batch, self.nslots, int(bool(want_surface)),
-                                             ctypes.byref(h)))
+        plan.eng._check(plan.eng.lib.caf_stream_create_ex(plan._h, self.batch, self.nslots, int(bool(want_surface)),
+                                                          _lib.CAF_STREAM_SPLIT if split else 0, ctypes.byref(h)))
         self._h = h
         plan._streams.add(self)
         self._cdt = np.complex128 if plan.dtype == "c128" else np.complex64

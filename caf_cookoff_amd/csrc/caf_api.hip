@@ -120,6 +120,7 @@ struct caf_plan {
     void *c_twM = nullptr, *c_th = nullptr;  // borrowed from the ctx cache
     DevBuf slab;                             // R = 4: per-workgroup scratch of the last radix-4 stage
     void *slab_override = nullptr;           // streaming slots bring their own
+    PeakStageOut stage_out = {nullptr, nullptr, nullptr};  // streaming capture: k_peak also writes the pinned result buffers
     bool bigq = false;          //   ... in its 16 x 4096 two-pass form (kernels_q65536.hpp)
     DevBuf bwork, bhwork, bpart_val, bpart_idx;
     double *d_freqs = nullptr;  // this shard's slice
@@ -1009,10 +1010,10 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
     // find_peak (mod.rs:31-42)
     if (p->dtype == CAF_C128)
         k_peak<double><<<(unsigned)batch, 256, 0, c->stream>>>(p->d_freqs, d_ridx, (const double *)d_rval, (int)p->rows,
-                                                               (int64_t)p->row_begin, d_peak);
+                                                               (int64_t)p->row_begin, d_peak, p->stage_out);
     else
         k_peak<float><<<(unsigned)batch, 256, 0, c->stream>>>(p->d_freqs, d_ridx, (const float *)d_rval, (int)p->rows,
-                                                              (int64_t)p->row_begin, d_peak);
+                                                              (int64_t)p->row_begin, d_peak, p->stage_out);
     KCHK();
     return CAF_OK;
 }
@@ -1106,7 +1107,8 @@ extern "C" int caf_find_peak(caf_ctx *c, const double *freqs, const uint64_t *ro
         HIPCHK(hipMemcpyAsync(c->io_rval.p, row_val, nfreq * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     k_peak<double><<<1, 256, 0, c->stream>>>((const double *)c->io_a.p, (const uint64_t *)c->io_ridx.p,
-                                             (const double *)c->io_rval.p, (int)nfreq, 0, (caf_peak *)c->io_peak.p);
+                                             (const double *)c->io_rval.p, (int)nfreq, 0, (caf_peak *)c->io_peak.p,
+                                             PeakStageOut{nullptr, nullptr, nullptr});
     KCHK();
     HIPCHK(hipMemcpyAsync(peak, c->io_peak.p, sizeof(caf_peak), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1152,7 +1154,7 @@ struct StreamSlot {
     hipGraphExec_t exec = nullptr;
     void *h_needle = nullptr, *h_hay = nullptr;            // pinned
     void *h_peak = nullptr, *h_ridx = nullptr, *h_rval = nullptr;  // pinned results
-    void *d_needle = nullptr, *d_hay = nullptr, *d_surface = nullptr;
+    void *d_needle = nullptr, *d_surface = nullptr;  // (the haystack is read in place from h_hay)
     void *d_ridx = nullptr, *d_rval = nullptr, *d_peak = nullptr;
     void *d_spec = nullptr;  // fused / chain plans: this slot's haystack spectra
     void *d_slab = nullptr;  // chain plans with R = 4: this slot's radix-4 scratch
@@ -1175,7 +1177,7 @@ static void stream_free(caf_stream *st)
         if (s.graph) (void)hipGraphDestroy(s.graph);
         for (void *p : {s.h_needle, s.h_hay, s.h_peak, s.h_ridx, s.h_rval})
             if (p) (void)hipHostFree(p);
-        for (void *p : {s.d_needle, s.d_hay, s.d_surface, s.d_ridx, s.d_rval, s.d_peak, s.d_spec, s.d_slab})
+        for (void *p : {s.d_needle, s.d_surface, s.d_ridx, s.d_rval, s.d_peak, s.d_spec, s.d_slab})
             if (p) (void)hipFree(p);
         if (s.stream && s.own_stream) (void)hipStreamDestroy(s.stream);
     }
@@ -1183,11 +1185,15 @@ static void stream_free(caf_stream *st)
     delete st;
 }
 
-extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want_surface, caf_stream **out)
+extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int want_surface, unsigned flags,
+                                    caf_stream **out)
 {
     if (!p || !out) return fail(CAF_ERR_BAD_ARG, "caf_stream_create: NULL argument");
     *out = nullptr;
     if (batch == 0 || nslots < 2 || nslots > 16) return fail(CAF_ERR_BAD_ARG, "caf_stream_create: batch >= 1, 2 <= nslots <= 16");
+    if (flags & ~(unsigned)CAF_STREAM_SPLIT) return fail(CAF_ERR_BAD_ARG, "caf_stream_create_ex: unknown flags 0x%x", flags);
+    const bool split = (flags & CAF_STREAM_SPLIT) && batch > 1;
+    if (split && batch > 16) return fail(CAF_ERR_BAD_ARG, "caf_stream_create_ex: CAF_STREAM_SPLIT supports at most 16 surfaces per slot");
     caf_ctx *c = p->ctx;
     HIPCHK(hipSetDevice(c->device));
     caf_stream *st = new (std::nothrow) caf_stream;
@@ -1195,13 +1201,35 @@ extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want
     st->plan = p;
     st->batch = batch;
     st->slots.resize(nslots);
-    const size_t in_bytes = batch * p->n * elem_size(p->dtype);
+    const bool private_state = p->fused || p->chain;  // slots (and split branches) own their spectra / scratch
+    const size_t esz = elem_size(p->dtype), rsz = real_size(p->dtype);
+    const size_t in1 = p->n * esz, in_bytes = batch * in1;
     const size_t rows = p->rows ? p->rows : 1;
-    const size_t ridx_bytes = batch * rows * sizeof(uint64_t), rval_bytes = batch * rows * real_size(p->dtype);
-    const size_t surf_bytes = batch * rows * p->L * real_size(p->dtype);
+    const size_t ridx1 = rows * sizeof(uint64_t), rval1 = rows * rsz, surf1 = rows * p->L * rsz;
+    const size_t ridx_bytes = batch * ridx1, rval_bytes = batch * rval1, surf_bytes = batch * surf1;
+    // per-surface spectrum bytes (+256: the fused path's row-ticket word); split branches get one each
+    const size_t spec1 = p->fused ? (size_t)2 * 16 * 256 * esz : p->chain ? p->L * esz : 0;
+    const size_t spec_stride = split ? spec1 + 256 : 0;
+    const size_t slab1 = p->chain && p->cR == 4
+                             ? (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, esz) * 2 * 16 * (((size_t)1 << p->clogm) / 16) * esz
+                             : 0;
     hipStream_t saved = c->stream;
+    std::vector<hipStream_t> aux;   // capture-time fork streams of the split mode
+    std::vector<hipEvent_t> evs;
     int rc = CAF_OK;
-    auto bail = [&](int code) { c->stream = saved; p->spec_override = nullptr; p->slab_override = nullptr; stream_free(st); return code; };
+    auto cleanup_aux = [&]() {
+        for (auto e : evs) (void)hipEventDestroy(e);
+        for (auto a : aux) (void)hipStreamDestroy(a);
+        evs.clear();
+        aux.clear();
+    };
+    auto bail = [&](int code) {
+        c->stream = saved; p->spec_override = nullptr; p->slab_override = nullptr;
+        p->stage_out = PeakStageOut{nullptr, nullptr, nullptr};
+        cleanup_aux();
+        stream_free(st);
+        return code;
+    };
 #define SCHK(expr)                                                                                         \
     do {                                                                                                   \
         hipError_t e__ = (expr);                                                                           \
@@ -1211,26 +1239,20 @@ extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want
         StreamSlot &s = st->slots[si];
         // Fused / chain plans: every slot has private device state -> slots run concurrently on
         // their own streams.  tiled65536 / generic plans share the plan's pass workspaces -> one stream.
-        if (p->fused || p->chain || si == 0) {
+        if (private_state || si == 0) {
             SCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         } else {
             s.stream = st->slots[0].stream;
             s.own_stream = false;
         }
-        if (p->fused) SCHK(hipMalloc(&s.d_spec, batch * 2 * 16 * 256 * elem_size(p->dtype) + 256));
-        if (p->chain) {
-            SCHK(hipMalloc(&s.d_spec, batch * p->L * elem_size(p->dtype)));
-            if (p->cR == 4)
-                SCHK(hipMalloc(&s.d_slab, (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, elem_size(p->dtype)) * 2 * 16 *
-                                              ((size_t)1 << p->clogm) / 16 * elem_size(p->dtype)));
-        }
+        if (spec1) SCHK(hipMalloc(&s.d_spec, split ? batch * spec_stride : batch * spec1 + 256));
+        if (slab1) SCHK(hipMalloc(&s.d_slab, (split ? batch : 1) * slab1));
         SCHK(hipHostMalloc(&s.h_needle, in_bytes, hipHostMallocDefault));
         SCHK(hipHostMalloc(&s.h_hay, in_bytes, hipHostMallocDefault));
         SCHK(hipHostMalloc(&s.h_peak, batch * sizeof(caf_peak), hipHostMallocDefault));
         SCHK(hipHostMalloc(&s.h_ridx, ridx_bytes, hipHostMallocDefault));
         SCHK(hipHostMalloc(&s.h_rval, rval_bytes, hipHostMallocDefault));
         SCHK(hipMalloc(&s.d_needle, in_bytes));
-        SCHK(hipMalloc(&s.d_hay, in_bytes));
         SCHK(hipMalloc(&s.d_ridx, ridx_bytes));
         SCHK(hipMalloc(&s.d_rval, rval_bytes));
         SCHK(hipMalloc(&s.d_peak, batch * sizeof(caf_peak)));
@@ -1238,47 +1260,100 @@ extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want
         memset(s.h_needle, 0, in_bytes);
         memset(s.h_hay, 0, in_bytes);
     }
-    // Warm-up outside capture: lets the plan allocate its per-batch workspace (hipMalloc is
-    // not capturable), then capture one graph per slot on the slot's own stream.
-    c->stream = st->slots[0].stream;
+    const bool was_timing = p->timing;
+    const bool fork = split && private_state;  // parallel branches need private spectra; otherwise the chains run in series
+    if (fork) {
+        aux.resize(batch - 1);
+        for (auto &a : aux) { a = nullptr; SCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking)); }
+        evs.resize(batch);
+        for (auto &e : evs) { e = nullptr; SCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+    }
+    // One node chain = {stage-in, haystack spectrum, row kernel(s), find_peak, stage-out}: kernels only.
+    // Stage-in / stage-out read / write the slot's pinned host buffers through their device mappings
+    // (k_stage_copy).  Batched slot: ONE chain over `batch` surfaces.  CAF_STREAM_SPLIT: `batch`
+    // single-surface chains in the slot's one graph, as parallel branches when the plan's state is private.
+    auto chain = [&](StreamSlot &s, hipStream_t on, size_t first, size_t nsurf, void *spec, void *slab) -> int {
+        char *m_needle = nullptr, *m_hay = nullptr, *m_peak = nullptr, *m_ridx = nullptr, *m_rval = nullptr;
+        HIPCHK(hipHostGetDevicePointer((void **)&m_needle, s.h_needle, 0));
+        HIPCHK(hipHostGetDevicePointer((void **)&m_hay, s.h_hay, 0));
+        HIPCHK(hipHostGetDevicePointer((void **)&m_peak, s.h_peak, 0));
+        HIPCHK(hipHostGetDevicePointer((void **)&m_ridx, s.h_ridx, 0));
+        HIPCHK(hipHostGetDevicePointer((void **)&m_rval, s.h_rval, 0));
+        char *dn = (char *)s.d_needle + first * in1;
+        char *dp = (char *)s.d_peak + first * sizeof(caf_peak), *di = (char *)s.d_ridx + first * ridx1;
+        char *dv = (char *)s.d_rval + first * rval1;
+        char *ds = s.d_surface ? (char *)s.d_surface + first * surf1 : nullptr;
+        const size_t inb = nsurf * in1;
+        // needle: read twice per Doppler row -> staged into device memory by one kernel node;
+        // haystack: read once, by the haystack-spectrum kernel -> that kernel reads the pinned host
+        // buffer in place (no copy node); row peaks + caf_peak: written to the pinned result buffers by
+        // find_peak itself (no stage-out node).  A slot's chain is 4 kernel nodes on the fused path.
+        CopyJobs jin = {{m_needle + first * in1, nullptr, nullptr}, {dn, nullptr, nullptr}, {inb, 0, 0}};
+        const size_t in16 = (inb / 16 + 255) / 256;
+        c->stream = on;
+        p->spec_override = spec;
+        p->slab_override = slab;
+        p->stage_out = PeakStageOut{(caf_peak *)(m_peak + first * sizeof(caf_peak)), (uint64_t *)(m_ridx + first * ridx1),
+                                    (void *)(m_rval + first * rval1)};
+        k_stage_copy<<<(unsigned)(in16 < 1 ? 1 : in16 > 1024 ? 1024 : in16), 256, 0, on>>>(jin);
+        hipError_t e1 = hipGetLastError();
+        int r = caf_surface_dev(p, dn, m_hay + first * in1, nsurf, ds, (uint64_t *)di, dv, (caf_peak *)dp);
+        p->spec_override = nullptr;
+        p->slab_override = nullptr;
+        p->stage_out = PeakStageOut{nullptr, nullptr, nullptr};
+        if (r) return r;
+        if (e1 != hipSuccess) return fail(CAF_ERR_HIP, "stage copy launch: %s", hipGetErrorString(e1));
+        return CAF_OK;
+    };
+    // Warm-up outside capture: lets the plan allocate its workspaces (hipMalloc is not capturable)
     {
         StreamSlot &s = st->slots[0];
-        SCHK(hipMemcpyAsync(s.d_needle, s.h_needle, in_bytes, hipMemcpyHostToDevice, s.stream));
-        SCHK(hipMemcpyAsync(s.d_hay, s.h_hay, in_bytes, hipMemcpyHostToDevice, s.stream));
-        rc = caf_surface_dev(p, s.d_needle, s.d_hay, batch, s.d_surface, (uint64_t *)s.d_ridx, s.d_rval, (caf_peak *)s.d_peak);
+        rc = chain(s, s.stream, 0, split ? 1 : batch, s.d_spec, s.d_slab);
         if (rc) return bail(rc);
         SCHK(hipStreamSynchronize(s.stream));
     }
-    const bool was_timing = p->timing;
     p->timing = false;  // event records are not wanted inside the graphs
     for (auto &s : st->slots) {
-        c->stream = s.stream;
-        p->spec_override = s.d_spec;
-        p->slab_override = s.d_slab;
-        SCHK(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
-        hipError_t e1 = hipMemcpyAsync(s.d_needle, s.h_needle, in_bytes, hipMemcpyHostToDevice, s.stream);
-        hipError_t e2 = hipMemcpyAsync(s.d_hay, s.h_hay, in_bytes, hipMemcpyHostToDevice, s.stream);
-        rc = caf_surface_dev(p, s.d_needle, s.d_hay, batch, s.d_surface, (uint64_t *)s.d_ridx, s.d_rval, (caf_peak *)s.d_peak);
-        hipError_t e3 = hipMemcpyAsync(s.h_peak, s.d_peak, batch * sizeof(caf_peak), hipMemcpyDeviceToHost, s.stream);
-        hipError_t e4 = p->rows ? hipMemcpyAsync(s.h_ridx, s.d_ridx, ridx_bytes, hipMemcpyDeviceToHost, s.stream) : hipSuccess;
-        hipError_t e5 = p->rows ? hipMemcpyAsync(s.h_rval, s.d_rval, rval_bytes, hipMemcpyDeviceToHost, s.stream) : hipSuccess;
+        hipError_t eb = hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal);
+        if (eb != hipSuccess) { p->timing = was_timing; return bail(fail(CAF_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(eb))); }
+        hipError_t ef = hipSuccess;
+        if (!split) {
+            rc = chain(s, s.stream, 0, batch, s.d_spec, s.d_slab);
+        } else {
+            if (fork) ef = hipEventRecord(evs[0], s.stream);
+            for (size_t i = 0; i < batch && rc == CAF_OK && ef == hipSuccess; ++i) {
+                hipStream_t on = (fork && i > 0) ? aux[i - 1] : s.stream;
+                if (fork && i > 0) ef = hipStreamWaitEvent(on, evs[0], 0);
+                if (ef != hipSuccess) break;
+                rc = chain(s, on, i, 1, s.d_spec ? (char *)s.d_spec + i * spec_stride : nullptr,
+                           s.d_slab ? (char *)s.d_slab + i * slab1 : nullptr);
+                if (fork && i > 0 && rc == CAF_OK) {
+                    ef = hipEventRecord(evs[i], on);
+                    if (ef == hipSuccess) ef = hipStreamWaitEvent(s.stream, evs[i], 0);
+                }
+            }
+        }
         hipError_t ec = hipStreamEndCapture(s.stream, &s.graph);
-        p->spec_override = nullptr;
-        p->slab_override = nullptr;
         p->timing = was_timing;
         if (rc) return bail(rc);
-        for (hipError_t e : {e1, e2, e3, e4, e5, ec})
+        for (hipError_t e : {ef, ec})
             if (e != hipSuccess) return bail(fail(CAF_ERR_HIP, "graph capture: %s", hipGetErrorString(e)));
         SCHK(hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0));
         p->timing = false;
     }
     p->timing = was_timing;
 #undef SCHK
+    cleanup_aux();
     c->stream = saved;
     st->counted = true;
     ++p->live_streams;  // caf_plan_destroy / caf_ctx_destroy refuse while the graphs hold the plan's buffers
     *out = st;
     return CAF_OK;
+}
+
+extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want_surface, caf_stream **out)
+{
+    return caf_stream_create_ex(p, batch, nslots, want_surface, 0u, out);
 }
 
 extern "C" int caf_stream_destroy(caf_stream *st)

@@ -135,12 +135,19 @@ __global__ __launch_bounds__(256) void k_mag_argmax(const cpx<T> *__restrict__ c
 
 // find_peak (mod.rs:31-42): first row (list order) whose peak is strictly greater
 // than the running best, starting from (freq 0.0, idx 0, val 0.0).
-// One workgroup per batch entry.
+// One workgroup per batch entry.  Streaming slots (caf_stream_*) pass `host`: the device mappings
+// of the slot's pinned result buffers; the workgroup then also stages its surface's row peaks and
+// its caf_peak record out to host memory (the graph needs no separate stage-out node).
+struct PeakStageOut {
+    caf_peak *peak;      // [batch] or nullptr
+    uint64_t *row_idx;   // [batch][rows]
+    void *row_val;       // [batch][rows] of the plan's real type
+};
 template <typename T>
 __global__ __launch_bounds__(256) void k_peak(const double *__restrict__ freqs,
                                               const uint64_t *__restrict__ row_idx,
                                               const T *__restrict__ row_val, int rows,
-                                              int64_t row_base, caf_peak *__restrict__ out)
+                                              int64_t row_base, caf_peak *__restrict__ out, const PeakStageOut host)
 {
     __shared__ double s_v[4];
     __shared__ uint32_t s_i[4];
@@ -150,6 +157,10 @@ __global__ __launch_bounds__(256) void k_peak(const double *__restrict__ freqs,
     for (int r = threadIdx.x; r < rows; r += blockDim.x) {
         const double v = (double)row_val[b * rows + r];
         if (v > 0.0) arg_merge(bv, br, v, (uint32_t)r);
+        if (host.peak) {
+            host.row_idx[b * rows + r] = row_idx[b * rows + r];
+            ((T *)host.row_val)[b * rows + r] = row_val[b * rows + r];
+        }
     }
     wave_arg_reduce(bv, br);
     const int wave = threadIdx.x >> 6;
@@ -165,6 +176,7 @@ __global__ __launch_bounds__(256) void k_peak(const double *__restrict__ freqs,
             p.row = row_base + (int64_t)br;
         }
         out[b] = p;
+        if (host.peak) host.peak[b] = p;
     }
 }
 
@@ -178,6 +190,30 @@ __global__ void k_view(const T *__restrict__ surf, size_t L, size_t width, size_
     if (i >= width) return;
     const size_t src = (off + L - (i % L)) % L;
     out[r * width + i] = sqrt(surf[r * L + src]);
+}
+
+// Streaming stage-in / stage-out (caf_stream_*): up to three (src, dst, bytes) jobs copied by ONE
+// kernel node of the slot's graph.  One side of every job is PINNED HOST memory mapped into the
+// device address space (hipHostMalloc is coherent: device accesses are uncached), so the two
+// hipMemcpyAsync H2D nodes and the three D2H nodes of a slot become two kernel nodes, which replay
+// several microseconds faster than copy-engine nodes.  Sizes are multiples of 4 bytes; buffers are
+// 16-byte aligned.
+struct CopyJobs {
+    const void *src[3];
+    void *dst[3];
+    unsigned long long bytes[3];
+};
+__global__ __launch_bounds__(256) void k_stage_copy(const CopyJobs J)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const size_t n16 = J.bytes[j] / 16, n4 = (J.bytes[j] % 16) / 4;
+        const uint4 *s = (const uint4 *)J.src[j];
+        uint4 *d = (uint4 *)J.dst[j];
+        for (size_t i = tid; i < n16; i += nthr) d[i] = s[i];
+        if (tid < n4) ((uint32_t *)(d + n16))[tid] = ((const uint32_t *)(s + n16))[tid];
+    }
 }
 
 }  // namespace caf

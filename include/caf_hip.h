@@ -175,10 +175,11 @@ int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, 
 /* ---- streaming (BASELINE configs[4]) ----------------------------------------------
  * Back-to-back surfaces from host memory: `nslots` (>= 2) independent slots, each with
  * pinned host staging for `batch` (needle, haystack) pairs, its own device buffers, its
- * own HIP stream and ONE captured hipGraph {H2D needle, H2D haystack, haystack spectrum,
- * row kernel, find_peak, D2H of the row peaks + caf_peak records}.  While slot k computes,
- * the caller fills slot k+1's pinned buffers and submits it: its H2D overlaps slot k's
- * kernels.  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
+ * own HIP stream and ONE captured hipGraph {stage-in of needle + haystack, haystack spectrum,
+ * row kernel, find_peak, stage-out of the row peaks + caf_peak records}; stage-in / stage-out
+ * are kernel nodes that read / write the pinned buffers through their device mappings (they
+ * replay faster than copy-engine nodes).  While slot k computes, the caller fills slot k+1's
+ * pinned buffers and submits it: its H2D overlaps slot k's kernels.  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
  * only (tau, f) + per-row peaks come back, as SURVEY.md section 8d prescribes.
  * Plans whose row kernel keeps its intermediate data on-chip ("fused4096", "chain") give
  * every slot private device state, so slots execute concurrently.  Plans on the "tiled65536"
@@ -190,6 +191,15 @@ int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, 
  * destroys every plan that is still alive). */
 typedef struct caf_stream caf_stream;
 int caf_stream_create(caf_plan *plan, size_t batch, int nslots, int want_surface, caf_stream **out);
+/* Same with flags.  CAF_STREAM_SPLIT: the slot's ONE graph holds `batch` (<= 16) independent
+ * SINGLE-SURFACE node chains (each its own stage-in, haystack spectrum, row kernel, find_peak,
+ * stage-out) instead of one batched chain -- as parallel branches when the plan's per-slot state
+ * is private ("fused4096", "chain"), in series otherwise.  One replay then retires `batch`
+ * surfaces at single-surface granularity; host buffers and results are laid out as in the
+ * batched mode. */
+enum caf_stream_flags { CAF_STREAM_SPLIT = 1 };
+int caf_stream_create_ex(caf_plan *plan, size_t batch, int nslots, int want_surface, unsigned flags,
+                         caf_stream **out);
 int caf_stream_destroy(caf_stream *st);
 /* Pinned host buffers of a slot: [batch][n] complex each (dtype of the plan). */
 int caf_stream_host_buffers(caf_stream *st, int slot, void **needle, void **haystack);

@@ -343,3 +343,53 @@ def test_chain_streaming_slots(eng, oracle):
     finally:
         st.close()
         plan.close()
+
+
+@pytest.mark.parametrize("dtype", ["c128", "c64"])
+def test_streaming_split_mode_parity(dtype, eng, oracle):
+    """CAF_STREAM_SPLIT: four independent single-surface node chains per graph replay (parallel
+    branches, each with its own stage-in, spectrum buffer, row kernel and find_peak).  The ten
+    reference pairs cycled through two such slots give the bench-grid answers of the oracle; the row
+    peaks staged out by find_peak equal the batched mode's bit for bit."""
+    import caf_cookoff_amd as caf
+    fr = oracle.bench_shifts()
+    pairs = [oracle.load_pair(DATA, f"chirp_{k}_raw.c64", oracle.KATS[k][1]) for k in range(10)]
+    expect = []
+    for nd, hs in pairs:
+        _, oi, ov = oracle.np_caf_surface(nd, hs, fr, FS, want_surface=False)
+        expect.append(oracle.np_find_peak(fr, oi, ov) + (oi, ov))
+    plan = eng.plan(4096, fr, FS, dtype=dtype)
+    results = {}
+    for split in (True, False):
+        st = caf.Stream(plan, batch=4, nslots=2, want_surface=False, split=split)
+        got = {}
+        order = [(0, (0, 1, 2, 3)), (1, (4, 5, 6, 7)), (0, (8, 9, 0, 1)), (1, (2, 3, 4, 5))]
+        pending = []
+        for slot, ks in order:
+            if len(pending) == 2:
+                ps, pks = pending.pop(0)
+                peaks, ridx, rval = st.wait(ps)
+                for j, k in enumerate(pks):
+                    got[k] = (float(peaks[j]["freq"]), int(peaks[j]["idx"]), ridx[j].copy(), rval[j].copy())
+            a, b = st.buffers(slot)
+            for j, k in enumerate(ks):
+                a[j], b[j] = pairs[k]
+            st.submit(slot)
+            pending.append((slot, ks))
+        for ps, pks in pending:
+            peaks, ridx, rval = st.wait(ps)
+            for j, k in enumerate(pks):
+                got[k] = (float(peaks[j]["freq"]), int(peaks[j]["idx"]), ridx[j].copy(), rval[j].copy())
+        st.close()
+        results[split] = got
+    plan.close()
+    tol = TOL64 if dtype == "c128" else TOL32
+    for k in range(10):
+        ef, ei, oi, ov = expect[k]
+        f, i, ri, rv = results[True][k]
+        assert i == ei, f"chirp_{k}"
+        if dtype == "c128":
+            assert f == ef and np.array_equal(ri, oi)
+        assert np.max(np.abs(rv.astype(np.float64) - ov)) <= tol * ov.max()
+        fb, ib, rib, rvb = results[False][k]
+        assert (f, i) == (fb, ib) and np.array_equal(ri, rib) and np.array_equal(rv, rvb)
