@@ -387,7 +387,14 @@ static bool chain_config(size_t n, int dtype, int *logm, int *R)
 }
 
 // CHAIN_DISPATCH(T, logm, R, STMT): run STMT with constexpr LOGM_ / R_ for the instantiated combinations
-#define CHAIN_CASE(LG, RR, STMT) if (logm_ == LG && R_rt == RR) { constexpr int LOGM_ = LG; constexpr int R_ = RR; STMT; } else
+#define CHAIN_CASE(LG, RR, STMT)                                                                  \
+    if (logm_ == LG && R_rt == RR) {                                                             \
+        constexpr int LOGM_ = LG;                                                                \
+        constexpr int R_ = RR;                                                                   \
+        constexpr int NB_ = chain_nb_v(LG, sizeof(cpx<T>));                                      \
+        (void)NB_;                                                                               \
+        STMT;                                                                                    \
+    } else
 #define CHAIN_DISPATCH(T, logm, R, STMT)                                                               \
     do {                                                                                               \
         const int logm_ = (logm), R_rt = (R);                                                          \
@@ -575,7 +582,8 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
     const bool f64 = p->dtype == CAF_C128;
     if (p->chain) {
         static thread_local char name[64];
-        snprintf(name, sizeof name, "caf::k_chain_rows<%s, %d, %d>", f64 ? "double" : "float", p->clogm, p->cR);
+        snprintf(name, sizeof name, "caf::k_chain_rows<%s, %d, %d, %d, 0>", f64 ? "double" : "float", p->clogm, p->cR,
+                 chain_nb_v(p->clogm, f64 ? 16 : 8));
         return name;
     }
     if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";  // measurement build
@@ -832,13 +840,15 @@ static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_ha
     a.rows = (int)p->rows;
     a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr; a.slab = nullptr;
     const cpx<T> *phasor = (const cpx<T> *)p->d_phasor;
-    const size_t cap = (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, sizeof(cpx<T>));
+    const int nb = chain_nb_v(p->clogm, sizeof(cpx<T>));
+    const size_t cap = (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, sizeof(cpx<T>), nb);
+    const size_t cap_prep = (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, sizeof(cpx<T>), 1);
     // haystack spectrum, once per surface (the reference recomputes it per row, xcor_rustfft.rs:58-59)
     a.sig = (const cpx<T> *)d_hay;
     a.total = (int)batch;
     {
         const size_t want = (size_t)R * batch;
-        const unsigned grid = (unsigned)(want < cap ? want : cap);
+        const unsigned grid = (unsigned)(want < cap_prep ? want : cap_prep);
         CHAIN_DISPATCH(T, p->clogm, R, (k_chain_prepare<T, LOGM_, R_><<<grid, W, 0, c->stream>>>(a, phasor)));
     }
     KCHK();
@@ -855,7 +865,28 @@ static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_ha
     a.row_idx = d_ridx;
     a.row_val = (T *)d_rval;
     if ((rc = timing_mark(p))) return rc;
-    CHAIN_DISPATCH(T, p->clogm, R, (k_chain_rows<T, LOGM_, R_><<<grid, W, 0, c->stream>>>(a, phasor)));
+#ifdef CAF_MEASURE
+    // CAF_CHAIN_ABL (bit mask, kernels_chain.hpp ChainLane): ablations of the configs[3] kernel, WRONG results
+    if constexpr (sizeof(T) == 4) {
+        const int abl = (int)measure_env("CAF_CHAIN_ABL", 0);
+        if (abl && p->clogm == 14 && R == 4) {
+            switch (abl) {
+            case 1: k_chain_rows<T, 14, 4, 1, 1><<<grid, W, 0, c->stream>>>(a, phasor); break;
+            case 2: k_chain_rows<T, 14, 4, 1, 2><<<grid, W, 0, c->stream>>>(a, phasor); break;
+            case 4: k_chain_rows<T, 14, 4, 1, 4><<<grid, W, 0, c->stream>>>(a, phasor); break;
+            case 8: k_chain_rows<T, 14, 4, 1, 8><<<grid, W, 0, c->stream>>>(a, phasor); break;
+            case 16: k_chain_rows<T, 14, 4, 1, 16><<<grid, W, 0, c->stream>>>(a, phasor); break;
+            case 30: k_chain_rows<T, 14, 4, 1, 30><<<grid, W, 0, c->stream>>>(a, phasor); break;
+            case 31: k_chain_rows<T, 14, 4, 1, 31><<<grid, W, 0, c->stream>>>(a, phasor); break;
+            case 200: k_chain_rows<T, 14, 4, 2, 0><<<grid, W / 2, 0, c->stream>>>(a, phasor); break;  // two butterflies per thread (correct results)
+            default: return fail(CAF_ERR_BAD_ARG, "CAF_CHAIN_ABL=%d: no such ablation", abl);
+            }
+            KCHK();
+            return timing_mark(p);
+        }
+    }
+#endif
+    CHAIN_DISPATCH(T, p->clogm, R, (k_chain_rows<T, LOGM_, R_, NB_><<<grid, W / NB_, 0, c->stream>>>(a, phasor)));
     KCHK();
     if ((rc = timing_mark(p))) return rc;
     return CAF_OK;
@@ -1211,7 +1242,8 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     const size_t spec1 = p->fused ? (size_t)2 * 16 * 256 * esz : p->chain ? p->L * esz : 0;
     const size_t spec_stride = split ? spec1 + 256 : 0;
     const size_t slab1 = p->chain && p->cR == 4
-                             ? (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, esz) * 2 * 16 * (((size_t)1 << p->clogm) / 16) * esz
+                             ? (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, esz, chain_nb_v(p->clogm, esz)) * 2 * 16 *
+                                   (((size_t)1 << p->clogm) / 16) * esz
                              : 0;
     hipStream_t saved = c->stream;
     std::vector<hipStream_t> aux;   // capture-time fork streams of the split mode

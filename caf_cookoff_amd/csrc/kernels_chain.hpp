@@ -61,24 +61,26 @@ constexpr size_t chain_lds_bytes_v(int logm, size_t csize)
     return (M + M / 16 + M / 16 + M / 256 + 16) * csize + 256;
 }
 // waves per SIMD the register allocator must leave room for (csize = sizeof(complex))
-constexpr int chain_wps_v(int logm, size_t csize)
+constexpr int chain_wps_v(int logm, size_t csize, int nb = 1)
 {
-    const int W = (1 << logm) / 16;
+    const int W = (1 << logm) / 16 / nb;  // threads per workgroup
     const int waves_wg = (W + 63) / 64;
     const int by_lds = (int)(160 * 1024 / chain_lds_bytes_v(logm, csize));
     const int per_simd = (waves_wg * (by_lds < 1 ? 1 : by_lds) + 3) / 4;  // what LDS lets reside
-    const int cap = csize == 16 ? 2 : 4;                                  // 256 / 128 VGPRs
+    const int cap = (csize == 16 || nb > 1) ? 2 : 4;                      // 256 / 128 VGPRs
     const int floor_ = (waves_wg + 3) / 4;                                // one workgroup must fit
     return per_simd < cap ? (per_simd < floor_ ? floor_ : per_simd) : (cap < floor_ ? floor_ : cap);
 }
 // resident workgroups per CU
-constexpr size_t chain_wg_per_cu_v(int logm, size_t csize)
+constexpr size_t chain_wg_per_cu_v(int logm, size_t csize, int nb = 1)
 {
-    const size_t W = ((size_t)1 << logm) / 16, waves_wg = (W + 63) / 64;
+    const size_t W = ((size_t)1 << logm) / 16 / nb, waves_wg = (W + 63) / 64;
     size_t per_cu = 160 * 1024 / chain_lds_bytes_v(logm, csize);
-    if (per_cu * waves_wg > (size_t)chain_wps_v(logm, csize) * 4) per_cu = (size_t)chain_wps_v(logm, csize) * 4 / waves_wg;
+    if (per_cu * waves_wg > (size_t)chain_wps_v(logm, csize, nb) * 4) per_cu = (size_t)chain_wps_v(logm, csize, nb) * 4 / waves_wg;
     return per_cu < 1 ? 1 : per_cu;
 }
+// butterflies per thread of the row kernel (see ChainLane: two was measured and lost)
+constexpr int chain_nb_v(int, size_t) { return 1; }
 template <typename T, int LOGM>
 constexpr size_t chain_lds_bytes() { return chain_lds_bytes_v(LOGM, sizeof(cpx<T>)); }
 template <typename T, int LOGM>
@@ -131,7 +133,7 @@ __global__ void k_chain_phasors(const double *__restrict__ ph, int nrows, int M,
 template <typename T>
 struct ChainArgs {
     const cpx<T> *sig;      // prepare: haystack [batch][n]; rows: needle [batch][n]
-    cpx<T> *spec;           // Hs [batch][R][16][W]: prepare writes, rows read
+    cpx<T> *spec;           // Hs [batch][R][8 register pairs][W][2]: prepare writes, rows read (one 16/32-byte access per pair)
     const cpx<T> *twM;      // [M]
     const cpx<T> *th;       // [(R-1) W]
     T *surface;             // [batch][rows][L] or nullptr
@@ -176,19 +178,35 @@ __device__ __forceinline__ void small_stage(cpx<T> (&v)[16])
     }
 }
 
-// Per-thread geometry + tables of one workgroup
-template <typename T, int LOGM>
+// Per-thread geometry + tables of one workgroup.  A thread owns NB butterflies per stage
+// ("slots" b = 0 .. NB-1: butterfly ids beta_b = t + b * W/NB, W = M/16).  The product uses NB = 1.
+// With NB = 2 a workgroup has half the waves, each with twice the registers, and a wave's two slots
+// are software-pipelined against each other through the wave-local exchanges (slot A's LDS writes
+// and reads in flight while the wave computes slot B's butterfly).  Motivation: all waves of a
+// workgroup run the same phase at the same time, so the LDS phases and the VALU phases of a CU do
+// not overlap (n = 32768 complex64: VALU 35 % busy + LDS 31 % busy, waves parked 56 % --
+// profiles/r02_c3; without any global memory the kernel still takes 0.91 of 1.50 ms).  Measured
+// (parity-green, CAF_CHAIN_ABL=200 of the measurement build): NB = 2 is SLOWER, 1.60 vs 1.39 ms, and
+// 1.02 vs 0.91 ms without global memory: two waves per SIMD with 116 spilled registers, and a
+// 4-bit lgkmcnt cannot wait for "all but the other slot's 32 operations".
+// ABL (measurement build only, WRONG results, timing only): bit 0 = no workgroup barriers, bit 1 = no
+// haystack-spectrum loads, bit 2 = no slab traffic, bit 3 = no needle loads, bit 4 = no surface stores.
+template <typename T, int LOGM, int NB = 1, int ABL = 0>
 struct ChainLane {
     using G = ChainGeo<LOGM>;
     using C = cpx<T>;
+    static constexpr int TH = G::W / NB;  // threads per workgroup
+    static_assert(G::W % NB == 0 && (TH % 64 == 0 || NB == 1), "slots must be whole waves apart");
+    static_assert(G::NST < 3 || G::local_after(1), "exchanges after stage 1 are assumed wave-local");
     int t;
-    int base[3];   // LDS base position of radix-16 stages 0..2
-    int o[3];      // t % S_s
-    int basef;     // last small stage / S = 1 stage: 17 t
-    C *Lc;         // chain
-    const C *tw1;  // LDS [16][S_1]
-    const C *tw2;  // LDS [16][S_2]
-    TwSet<T> tw;   // stage-0 twiddles W_M^(t k), k in {1,2,3,4,8,12}
+    int beta[NB];     // butterfly id of slot b
+    int base[NB][3];  // LDS base position of radix-16 stages 0..2
+    int o[NB][3];     // beta % S_s
+    int basef[NB];    // last small stage / S = 1 stage: 17 beta
+    C *Lc;            // chain
+    const C *tw1;     // LDS [16][S_1]
+    const C *tw2;     // LDS [16][S_2]
+    TwSet<T> tw[NB];  // stage-0 twiddles W_M^(beta k), k in {1,2,3,4,8,12}
 
     __device__ __forceinline__ ChainLane(unsigned char *smem, const C *__restrict__ twM)
     {
@@ -199,32 +217,37 @@ struct ChainLane {
         tw1 = tab1;
         tw2 = tab2;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            if (s < G::NS) {
-                const int S = G::str(s), B = G::blk(s);
-                const int g = t / S, oo = t % S;
-                o[s] = oo;
-                base[s] = g * (B + B / 16) + oo + (S >= 16 ? (oo >> 4) : 0);
-            } else {
-                o[s] = 0;
-                base[s] = 0;
+        for (int b = 0; b < NB; ++b) {
+            const int be = t + b * TH;
+            beta[b] = be;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                if (s < G::NS) {
+                    const int S = G::str(s), B = G::blk(s);
+                    const int g = be / S, oo = be % S;
+                    o[b][s] = oo;
+                    base[b][s] = g * (B + B / 16) + oo + (S >= 16 ? (oo >> 4) : 0);
+                } else {
+                    o[b][s] = 0;
+                    base[b][s] = 0;
+                }
             }
+            basef[b] = 17 * be;
+            tw[b].w1 = twM[be * 1];
+            tw[b].w2 = twM[be * 2];
+            tw[b].w3 = twM[be * 3];
+            tw[b].w4 = twM[be * 4];
+            tw[b].w8 = twM[be * 8];
+            tw[b].w12 = twM[be * 12];
         }
-        basef = 17 * t;
-        tw.w1 = twM[t * 1];
-        tw.w2 = twM[t * 2];
-        tw.w3 = twM[t * 3];
-        tw.w4 = twM[t * 4];
-        tw.w8 = twM[t * 8];
-        tw.w12 = twM[t * 12];
         // stage tables [k][o] = W_{B_s}^(o k) = twM[o k M / B_s]
         if constexpr (G::NS >= 2 && G::str(1) > 1) {
             constexpr int S = G::str(1), B = G::blk(1);
-            for (int i = t; i < 16 * S; i += G::W) tab1[i] = twM[(i % S) * (i / S) * (G::M / B)];
+            for (int i = t; i < 16 * S; i += TH) tab1[i] = twM[(i % S) * (i / S) * (G::M / B)];
         }
         if constexpr (G::NS >= 3 && G::str(2) > 1) {
             constexpr int S = G::str(2), B = G::blk(2);
-            for (int i = t; i < 16 * S; i += G::W) tab2[i] = twM[(i % S) * (i / S) * (G::M / B)];
+            for (int i = t; i < 16 * S; i += TH) tab2[i] = twM[(i % S) * (i / S) * (G::M / B)];
         }
     }
 
@@ -232,111 +255,131 @@ struct ChainLane {
     template <int S>
     __device__ __forceinline__ void sync_after() const
     {
-        if constexpr (G::local_after(S))
+        if constexpr (G::local_after(S) || (ABL & 1))
             wave_lds_fence();
         else
             __syncthreads();
     }
     template <int S>
-    __device__ __forceinline__ void read_stage(C (&v)[16]) const
+    static constexpr bool strided() { return S < G::NS && G::str(S < G::NS ? S : 0) > 1; }
+    template <int S>
+    __device__ __forceinline__ void rd(C (&v)[16], int b) const
     {
-        if constexpr (S < G::NS && G::str(S < G::NS ? S : 0) > 1) {
+        if constexpr (strided<S>()) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = Lc[base[S] + G::off(S, j)];
+            for (int j = 0; j < 16; ++j) v[j] = Lc[base[b][S < 3 ? S : 0] + G::off(S, j)];
         } else {  // S = 1 radix-16 stage or the small last stage: 16 contiguous elements
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = Lc[basef + j];
+            for (int j = 0; j < 16; ++j) v[j] = Lc[basef[b] + j];
         }
     }
     template <int S>
-    __device__ __forceinline__ void write_stage(const C (&v)[16]) const
+    __device__ __forceinline__ void wr(const C (&v)[16], int b) const
     {
-        if constexpr (S < G::NS && G::str(S < G::NS ? S : 0) > 1) {
+        if constexpr (strided<S>()) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) Lc[base[S] + G::off(S, j)] = v[j];
+            for (int j = 0; j < 16; ++j) Lc[base[b][S < 3 ? S : 0] + G::off(S, j)] = v[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) Lc[basef + j] = v[j];
+            for (int j = 0; j < 16; ++j) Lc[basef[b] + j] = v[j];
         }
     }
     // twiddle W_{B_S}^(o k) of radix-16 stage S >= 1 from its LDS table
     template <int S>
-    __device__ __forceinline__ C twk(int k) const
+    __device__ __forceinline__ C twk(int k, int b) const
     {
         constexpr int St = G::str(S < G::NS ? S : 0);
-        return (S == 1 ? tw1 : tw2)[k * St + o[S]];
+        return (S == 1 ? tw1 : tw2)[k * St + o[b][S < 3 ? S : 0]];
     }
-
-    // Forward DIF chain.  In: v[q] = u[t + W q] WITHOUT the lane-common factor `lane`, which is
-    // folded into the stage-0 output twiddles.  Out: v[k] = G[...] in this path's register layout.
-    __device__ __forceinline__ void forward(C (&v)[16], const C lane) const
+    // the last stage of the forward / first of the inverse: no twiddle, no memory
+    __device__ __forceinline__ void c_last(C (&v)[16]) const
     {
-        const TwFold<T> f0(tw, lane);
-        if constexpr (G::NST == 1) {  // (not instantiated: LOGM >= 8)
-            dft16(v);
-            return;
-        }
-        dft16_sink(v, [&](int k, C x) { Lc[base[0] + G::off(0, k)] = twA_k(x, k, tw, f0); });
-        sync_after<0>();
-        stage_fwd<1>(v);
-    }
-    template <int S>
-    __device__ __forceinline__ void stage_fwd(C (&v)[16]) const
-    {
-        read_stage<S>(v);
-        if constexpr (S >= G::NS) {  // the small last stage
+        if constexpr (G::RL > 1)
             small_stage<T, G::RL>(v);
-        } else if constexpr (S == G::NST - 1) {  // last stage is a radix-16 one (S_s = 1): no twiddle, stays in registers
+        else
             dft16(v);
+    }
+
+    // Forward DIF chain over the NB slots.  In: v[b][q] = u[beta_b + W q] WITHOUT the lane-common factor
+    // lane[b], which is folded into the stage-0 output twiddles.  Out: v[b][k] in this path's layout.
+    __device__ __forceinline__ void forward(C (&v)[NB][16], const C (&lane)[NB]) const
+    {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const TwFold<T> f0(tw[b], lane[b]);
+            dft16_sink(v[b], [&](int k, C x) { Lc[base[b][0] + G::off(0, k)] = twA_k(x, k, tw[b], f0); });
+        }
+        sync_after<0>();
+#pragma unroll
+        for (int b = 0; b < NB; ++b) rd<1>(v[b], b);
+        fwd_steps<1>(v);
+    }
+    // stage S of every slot; slot b's write + next read are in flight while slot b+1 computes
+    template <int S>
+    __device__ __forceinline__ void fwd_steps(C (&v)[NB][16]) const
+    {
+        if constexpr (S == G::NST - 1) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) c_last(v[b]);
         } else {
-            dft16_sink(v, [&](int k, C x) { Lc[base[S] + G::off(S, k)] = k ? cmul(x, twk<S>(k)) : x; });
-            sync_after<S>();
-            stage_fwd<S + 1>(v);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                dft16_sink(v[b], [&](int k, C x) { Lc[base[b][S < 3 ? S : 0] + G::off(S, k)] = k ? cmul(x, twk<S>(k, b)) : x; });
+                sync_after<S>();  // wave-local (static_assert above)
+                rd<S + 1>(v[b], b);
+                if constexpr (NB > 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            fwd_steps<S + 1>(v);
         }
     }
 
-    // Inverse DIT chain (mirror).  In: v[k] in the forward's output layout.  Out: v[i] = y[t + W i]
-    // BEFORE the stage-0 butterfly's input twiddle is applied by the caller-supplied functor
-    // `tw0(k, x)` (so a per-chain lane factor can ride on it), i.e. this function ends with
-    // dft16 of tw0-twiddled inputs.
+    // Inverse DIT chain (mirror).  In: v[b][k] in the forward's output layout.  Out: v[b][i] =
+    // y[beta_b + W i]; the stage-0 butterfly's input twiddle is applied by the caller-supplied functor
+    // tw0(b, k, x) (so a per-chain lane factor can ride on it).
     template <typename F>
-    __device__ __forceinline__ void inverse(C (&v)[16], F &&tw0) const
+    __device__ __forceinline__ void inverse(C (&v)[NB][16], F &&tw0) const
     {
-        stage_inv<G::NST - 1>(v);
+        inv_steps<G::NST - 1>(v);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = tw0(k, v[k]);
-        dft16(v);
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[b][k] = tw0(b, k, v[b][k]);
+            dft16(v[b]);
+        }
     }
     template <int S>
-    __device__ __forceinline__ void stage_inv(C (&v)[16]) const
+    __device__ __forceinline__ void inv_steps(C (&v)[NB][16]) const
     {
-        if constexpr (S == 0) {
+        static_assert(S >= 1, "stage 0 is finished by inverse()");
+        constexpr bool local = G::local_after(S - 1) || (ABL & 1);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = Lc[base[0] + G::off(0, j)];
-            return;
-        } else {
-            if constexpr (S >= G::NS) {
-                small_stage<T, G::RL>(v);
+        for (int b = 0; b < NB; ++b) {
+            if constexpr (S == G::NST - 1) {
+                c_last(v[b]);
                 wave_lds_fence();  // this thread's forward reads of the same 16 positions are done (program order)
-                write_stage<S>(v);
-            } else if constexpr (S == G::NST - 1) {
-                dft16(v);
-                wave_lds_fence();
-                write_stage<S>(v);
+                wr<S>(v[b], b);
             } else {
-                read_stage<S>(v);
 #pragma unroll
-                for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twk<S>(k));
+                for (int k = 1; k < 16; ++k) v[b][k] = cmul(v[b][k], twk<S>(k, b));
                 wave_lds_fence();
-                dft16_sink(v, [&](int k, C x) { Lc[base[S] + G::off(S, k)] = x; });
+                dft16_sink(v[b], [&](int k, C x) { Lc[base[b][S < 3 ? S : 0] + G::off(S, k)] = x; });
             }
-            sync_after<S - 1>();
-            stage_inv<S - 1>(v);
+            if constexpr (local) {
+                wave_lds_fence();
+                rd<S - 1>(v[b], b);
+                if constexpr (NB > 1) __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if constexpr (!local) {
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < NB; ++b) rd<S - 1>(v[b], b);
+        }
+        if constexpr (S - 1 >= 1) inv_steps<S - 1>(v);
     }
 };
 
-// lane-common phasor w^t from the three-level table of a row
+// lane-common phasor w^beta from the three-level table of a row
 template <typename T, int LOGM>
 __device__ __forceinline__ cpx<T> chain_pb(const cpx<T> *__restrict__ ph, int t)
 {
@@ -345,43 +388,57 @@ __device__ __forceinline__ cpx<T> chain_pb(const cpx<T> *__restrict__ ph, int t)
     return pb;
 }
 
-// chain input: v[q] = conj(x[q] * step_r[q]),  x = a0 (R = 2) or a0 + (-i)^r wM a1 (R = 4).
-// The samples are fetched in groups of four register rows, one group ahead of its use: at most
-// 2 x 4 (R = 2) / 2 x 8 (R = 4) loads are in flight.  Hoisting all 16 / 32 of them (what the
-// scheduler does on its own) costs 32 / 64 VGPRs on top of the 64 the two chains' data need and
-// spills at four waves per SIMD.
-template <typename T, int LOGM, int R>
-__device__ __forceinline__ void chain_input(cpx<T> (&v)[16], const __amdgpu_buffer_rsrc_t rs_sig, int r, int t,
-                                            const cpx<T> *__restrict__ ph)
+// Inputs of TWO chains from one pass over the needle samples: chains (rA, rB) = (0, 1) for R = 2,
+// (0, 2) and (1, 3) for R = 4 read the same a0 (and b = wM a1):
+//   v_r[q] = conj(x_r[q] * step_r[q]),  x_rA = a0 + s b, x_rB = a0 - s b, s = (-i)^rA   (R = 2: x = a0).
+// The second chain's input waits in registers while the first chain runs -- the same registers that
+// afterwards hold the first chain's result while the second runs -- so sharing the loads costs no
+// register and halves the needle traffic (L2 -> CU).  The samples are fetched in groups, one group
+// ahead of its use: hoisting all of them (what the scheduler does on its own) costs 32-64 VGPRs.
+template <typename T, int LOGM, int R, int ABL = 0>
+__device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[16], const __amdgpu_buffer_rsrc_t rs_sig,
+                                                 int rA, int rB, int beta, const cpx<T> *__restrict__ ph)
 {
     using C = cpx<T>;
     constexpr int W = ChainGeo<LOGM>::W, M = ChainGeo<LOGM>::M;
-    const C *ps = ph + 48 + 16 * r;
-    const unsigned voff = (unsigned)(t * sizeof(C));
+    constexpr int GQ = (R == 4 && sizeof(T) == 4) ? 2 : 4;  // register rows per fetch group (two groups in flight)
+    const C *psA = ph + 48 + 16 * rA, *psB = ph + 48 + 16 * rB;
+    const unsigned voff = (unsigned)(beta * sizeof(C));
     C wM = C{T(1), T(0)};
     if constexpr (R == 4) wM = ph[112];
-    C a0[2][4], a1[2][4];
+    C a0[2][GQ], a1[2][GQ];
     auto fetch = [&](int grp) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = 4 * grp + u;
+        for (int u = 0; u < GQ; ++u) {
+            const int q = GQ * grp + u;
+            if constexpr (ABL & 8) {
+                a0[grp & 1][u] = C{T(q + 1), T(beta)};
+                a1[grp & 1][u] = C{T(beta), T(q)};
+                keep(a0[grp & 1][u]);
+                keep(a1[grp & 1][u]);
+                continue;
+            }
             a0[grp & 1][u] = bload(rs_sig, voff, (unsigned)(W * q * sizeof(C)), (C *)nullptr);
             if constexpr (R == 4) a1[grp & 1][u] = bload(rs_sig, voff, (unsigned)((M + W * q) * sizeof(C)), (C *)nullptr);
         }
     };
     fetch(0);
 #pragma unroll
-    for (int grp = 0; grp < 4; ++grp) {
-        if (grp < 3) fetch(grp + 1);
+    for (int grp = 0; grp < 16 / GQ; ++grp) {
+        if (grp < 16 / GQ - 1) fetch(grp + 1);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = 4 * grp + u;
-            C x = a0[grp & 1][u];
+        for (int u = 0; u < GQ; ++u) {
+            const int q = GQ * grp + u;
+            const C x = a0[grp & 1][u];
             if constexpr (R == 4) {
                 const C b = cmul(a1[grp & 1][u], wM);
-                x = r == 0 ? x + b : r == 1 ? sub_i(x, b) : r == 2 ? x - b : add_i(x, b);
+                // rA = 0: x +- b;  rA = 1: x -+ i b
+                vA[q] = cmul_conj(rA == 0 ? x + b : sub_i(x, b), psA[q]);
+                vB[q] = cmul_conj(rA == 0 ? x - b : add_i(x, b), psB[q]);
+            } else {
+                vA[q] = cmul_conj(x, psA[q]);
+                vB[q] = cmul_conj(x, psB[q]);
             }
-            v[q] = cmul_conj(x, ps[q]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -407,15 +464,35 @@ __device__ constexpr double W64S[32] = {
     0.55557023301960222474, 0.47139673682599764856, 0.38268343236508977173, 0.29028467725446236764,
     0.19509032201612826785, 0.09801714032956060199};
 
+// chain input of ONE chain (the haystack transform; not on the row path)
+template <typename T, int LOGM, int R>
+__device__ __forceinline__ void chain_input_one(cpx<T> (&v)[16], const __amdgpu_buffer_rsrc_t rs_sig, int r, int beta,
+                                                const cpx<T> *__restrict__ ph)
+{
+    using C = cpx<T>;
+    constexpr int W = ChainGeo<LOGM>::W, M = ChainGeo<LOGM>::M;
+    const C *ps = ph + 48 + 16 * r;
+    const unsigned voff = (unsigned)(beta * sizeof(C));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        C x = bload(rs_sig, voff, (unsigned)(W * q * sizeof(C)), (C *)nullptr);
+        if constexpr (R == 4) {
+            const C b = bload(rs_sig, voff, (unsigned)((M + W * q) * sizeof(C)), (C *)nullptr);  // w = 1: wM = 1
+            x = r == 0 ? x + b : r == 1 ? sub_i(x, b) : r == 2 ? x - b : add_i(x, b);
+        }
+        v[q] = cmul_conj(x, ps[q]);
+    }
+}
+
 // ---- haystack spectrum: one workgroup per (surface, chain) ------------------------------------
-// Hs = FFT_L(haystack ++ 0)/L = conj(IDFT_L(conj h))/L, register layout spec[b][r][k][t].
+// Hs = FFT_L(haystack ++ 0)/L = conj(IDFT_L(conj h))/L, register layout spec[b][r][k][beta].
 template <typename T, int LOGM, int R>
 __global__ __launch_bounds__(ChainGeo<LOGM>::W) void k_chain_prepare(const ChainArgs<T> A, const cpx<T> *__restrict__ phasor)
 {
     using G = ChainGeo<LOGM>;
     using C = cpx<T>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[chain_lds_bytes<T, LOGM>()];
-    const ChainLane<T, LOGM> L(smem, A.twM);
+    const ChainLane<T, LOGM, 1> L(smem, A.twM);
     constexpr int NS_IN = R * G::M / 2;  // samples per input
     const C *__restrict__ ph = phasor + (size_t)A.rows * CH_PH;  // the f = 0 row
     const T inv = T(1.0 / (double)(R * G::M));
@@ -424,63 +501,73 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W) void k_chain_prepare(const Chain
         const int b = __builtin_amdgcn_readfirstlane(w / R), r = __builtin_amdgcn_readfirstlane(w % R);
         const __amdgpu_buffer_rsrc_t rs_sig = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.sig + (size_t)b * NS_IN), 0, NS_IN * (int)sizeof(C), 0x00020000);
-        C lane = chain_pb<T, LOGM>(ph, L.t);
-        if (r) lane = cmulc(lane, A.th[(r - 1) * G::W + L.t]);
-        C v[16];
-        chain_input<T, LOGM, R>(v, rs_sig, r, L.t, ph);
-        L.forward(v, conj(lane));
+        C lane[1] = {chain_pb<T, LOGM>(ph, L.t)};
+        if (r) lane[0] = cmulc(lane[0], A.th[(r - 1) * G::W + L.t]);
+        lane[0] = conj(lane[0]);
+        C v[1][16];
+        chain_input_one<T, LOGM, R>(v[0], rs_sig, r, L.t, ph);
+        L.forward(v, lane);
         C *spec = A.spec + ((size_t)b * R + r) * (16 * G::W);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) spec[k * G::W + L.t] = {v[k].x * inv, -v[k].y * inv};
+        for (int k = 0; k < 16; ++k) spec[((k >> 1) * G::W + L.t) * 2 + (k & 1)] = {v[0][k].x * inv, -v[0][k].y * inv};
         __syncthreads();  // the next iteration's stage-0 writes vs this one's reads by other waves
     }
 }
 
-// one chain of one row: needle -> y'_r[i] = th_r(t) * IDFT_M(Hs G_r)[t + W i]
-template <typename T, int LOGM, int R>
-__device__ __forceinline__ void chain_run(cpx<T> (&v)[16], const ChainLane<T, LOGM> &L, const ChainArgs<T> &A,
-                                          const __amdgpu_buffer_rsrc_t rs_sig, const __amdgpu_buffer_rsrc_t rs_spec, int r,
-                                          const cpx<T> pb, const cpx<T> *__restrict__ ph)
+// one chain of one row over the NB slots: v = chain input (chain_input_pair)
+//   -> y'_r[b][i] = th_r(beta_b) * IDFT_M(Hs G_r)[beta_b + W i]
+template <typename T, int LOGM, int R, int NB, int ABL>
+__device__ __forceinline__ void chain_run(cpx<T> (&v)[NB][16], const ChainLane<T, LOGM, NB, ABL> &L, const ChainArgs<T> &A,
+                                          const __amdgpu_buffer_rsrc_t rs_spec, int r, const cpx<T> (&pb)[NB])
 {
     using G = ChainGeo<LOGM>;
     using C = cpx<T>;
-    C lane = pb;
-    C post = C{T(1), T(0)};
-    if (r) {
-        post = A.th[(r - 1) * G::W + L.t];  // W_L^(t r)
-        lane = cmulc(lane, post);           // w^t e^{-2 pi i t r / L}
+    C lane[NB], post[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        post[b] = C{T(1), T(0)};
+        lane[b] = pb[b];
+        if (r) {
+            post[b] = A.th[(r - 1) * G::W + L.beta[b]];  // W_L^(beta r)
+            lane[b] = cmulc(lane[b], post[b]);            // w^beta e^{-2 pi i beta r / L}
+        }
+        lane[b] = conj(lane[b]);
     }
-    chain_input<T, LOGM, R>(v, rs_sig, r, L.t, ph);
-    L.forward(v, conj(lane));
-    const unsigned voff = (unsigned)((r * 16 * G::W + L.t) * sizeof(C));
+    L.forward(v, lane);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {  // two groups of eight loads (register pressure, see chain_input)
-        C h[8];
+    for (int b = 0; b < NB; ++b) {
+        const unsigned voff = (unsigned)((r * 16 * G::W + 2 * L.beta[b]) * sizeof(C));
 #pragma unroll
-        for (int k = 0; k < 8; ++k) h[k] = bload(rs_spec, voff, (unsigned)(G::W * (8 * half + k) * sizeof(C)), (C *)nullptr);
+        for (int half = 0; half < 2; ++half) {  // two groups of eight values (register pressure, see chain_input_pair)
+            C h[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[8 * half + k] = cmul(v[8 * half + k], h[k]);  // xcor_rustfft.rs:64-73
-        __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < 8; k += 2) {
+                if constexpr (ABL & 2) { h[k] = C{T(1), T(k)}; h[k + 1] = C{T(k), T(1)}; keep(h[k]); keep(h[k + 1]); continue; }
+                bload2(rs_spec, voff, (unsigned)(2 * G::W * (4 * half + k / 2) * sizeof(C)), h[k], h[k + 1]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[b][8 * half + k] = cmul(v[b][8 * half + k], h[k]);  // xcor_rustfft.rs:64-73
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     if (r) {
-        const TwFold<T> fpost(L.tw, post);
-        L.inverse(v, [&](int k, C x) { return twA_k(x, k, L.tw, fpost); });
+        L.inverse(v, [&](int b, int k, C x) { const TwFold<T> fpost(L.tw[b], post[b]); return twA_k(x, k, L.tw[b], fpost); });
     } else {
-        L.inverse(v, [&](int k, C x) { return twA_k(x, k, L.tw); });
+        L.inverse(v, [&](int b, int k, C x) { return twA_k(x, k, L.tw[b]); });
     }
 }
 
 // ---- the row kernel --------------------------------------------------------------------------------
-template <typename T, int LOGM, int R>
-__global__ __launch_bounds__(ChainGeo<LOGM>::W, chain_wps_v(LOGM, sizeof(cpx<T>))) void k_chain_rows(
+template <typename T, int LOGM, int R, int NB = 1, int ABL = 0>
+__global__ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB)) void k_chain_rows(
     const ChainArgs<T> A, const cpx<T> *__restrict__ phasor)
 {
     using G = ChainGeo<LOGM>;
     using C = cpx<T>;
     constexpr int W = G::W, M = G::M, Lp = R * M, NS_IN = R * M / 2;
-    constexpr int NW = (W + 63) / 64;  // waves per workgroup
+    constexpr int NWV = (W / NB + 63) / 64;  // waves per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char smem[chain_lds_bytes<T, LOGM>()];
-    const ChainLane<T, LOGM> L(smem, A.twM);
+    const ChainLane<T, LOGM, NB, ABL> L(smem, A.twM);
     unsigned char *const scratch = smem + chain_lds_bytes<T, LOGM>() - 256;  // per-wave argmax partials
     T *const sv = reinterpret_cast<T *>(scratch);
     uint32_t *const si = reinterpret_cast<uint32_t *>(scratch + 128);
@@ -490,79 +577,113 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W, chain_wps_v(LOGM, sizeof(cpx<T>)
     for (int g = blockIdx.x; g < A.total; g += gridDim.x) {
         // g is workgroup-uniform; the division runs on the VALU, so pin the results to SGPRs (a buffer
         // descriptor built from a VGPR value costs a waterfall loop per load)
-        const int b = __builtin_amdgcn_readfirstlane(g / A.rows);
-        const int r_row = __builtin_amdgcn_readfirstlane(g - b * A.rows);
+        const int bs = __builtin_amdgcn_readfirstlane(g / A.rows);
+        const int r_row = __builtin_amdgcn_readfirstlane(g - bs * A.rows);
         const C *__restrict__ ph = phasor + (size_t)r_row * CH_PH;
         const __amdgpu_buffer_rsrc_t rs_sig = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(A.sig + (size_t)b * NS_IN), 0, NS_IN * (int)sizeof(C), 0x00020000);
+            (void *)(A.sig + (size_t)bs * NS_IN), 0, NS_IN * (int)sizeof(C), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(A.spec + (size_t)b * R * 16 * W), 0, R * 16 * W * (int)sizeof(C), 0x00020000);
+            (void *)(A.spec + (size_t)bs * R * 16 * W), 0, R * 16 * W * (int)sizeof(C), 0x00020000);
         T *const out = A.surface ? A.surface + (size_t)g * Lp : nullptr;
         const __amdgpu_buffer_rsrc_t rs_out =
             __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? Lp * (int)sizeof(T) : 0, 0x00020000);
-        const C pb = chain_pb<T, LOGM>(ph, L.t);
-        const unsigned voff_out = (unsigned)(L.t * sizeof(T));
+        C pb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) pb[b] = chain_pb<T, LOGM>(ph, L.beta[b]);
 
         T bv[R];
         int bi[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) { bv[j] = T(0); bi[j] = 0; }
-        // mag of block j (lags m' + M j), register row i: store + first-strictly-greater running max
-        auto emit = [&](int j, int i, C c) {
+        // mag of block j (lags m' + M j, m' = beta_b + W i): store + first-strictly-greater running
+        // max; called with i outer, b inner, so the code i*NB + b increases with the lag inside a block
+        auto emit = [&](int j, int i, int b, C c) {
             const T m = norm_sqr(c);  // mod.rs:147
-            bi[j] = m > bv[j] ? i : bi[j];
+            bi[j] = m > bv[j] ? i * NB + b : bi[j];
             bv[j] = vmax(bv[j], m);
-            store_one_aux<CAF_AUX_SC1>(rs_out, voff_out, (unsigned)((M * j + W * i) * sizeof(T)), m);
+            if constexpr (ABL & 16) { asm volatile("" ::"v"(m)); return; }
+            store_one_aux<CAF_AUX_SC1>(rs_out, (unsigned)(L.beta[b] * sizeof(T)), (unsigned)((M * j + W * i) * sizeof(T)), m);
         };
 
         if constexpr (R == 2) {
-            C e[16], o[16];
-            chain_run<T, LOGM, R>(e, L, A, rs_sig, rs_spec, 0, pb, ph);
-            chain_run<T, LOGM, R>(o, L, A, rs_sig, rs_spec, 1, pb, ph);
+            C e[NB][16], o[NB][16];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) chain_input_pair<T, LOGM, R, ABL>(e[b], o[b], rs_sig, 0, 1, L.beta[b], ph);
+            chain_run<T, LOGM, R, NB, ABL>(e, L, A, rs_spec, 0, pb);
+            chain_run<T, LOGM, R, NB, ABL>(o, L, A, rs_spec, 1, pb);
             // c[m'] , c[m' + M] = E +- W_32^i (th O): th came folded into the odd chain's last twiddles
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                C lo, hi;
-                bfly_w(e[i], o[i], W32C16[i], W32S16[i], lo, hi);
-                emit(0, i, lo);
-                emit(1, i, hi);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    C lo, hi;
+                    bfly_w(e[b][i], o[b][i], W32C16[i], W32S16[i], lo, hi);
+                    emit(0, i, b, lo);
+                    emit(1, i, b, hi);
+                }
             }
         } else {
             // this workgroup's scratch slab through a buffer descriptor: per-lane byte offset in one VGPR,
             // the register-row offset in an SGPR (32 separate 64-bit global addresses would cost 64 VGPRs)
             const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(A.slab + (size_t)blockIdx.x * (2 * 16 * W)), 0, 2 * 16 * W * (int)sizeof(C), 0x00020000);
-            const unsigned voff_slab = (unsigned)(L.t * sizeof(C));
             {
-                C y0[16], y2[16];
-                chain_run<T, LOGM, R>(y0, L, A, rs_sig, rs_spec, 0, pb, ph);
-                chain_run<T, LOGM, R>(y2, L, A, rs_sig, rs_spec, 2, pb, ph);
+                C y0[NB][16], y2[NB][16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {  // a, b = y0 +- W_64^(2 i) y2'
-                    C a, bb;
-                    bfly_w(y0[i], y2[i], W64C[2 * i], W64S[2 * i], a, bb);
-                    bstore(rs_slab, voff_slab, (unsigned)(i * W * sizeof(C)), a);
-                    bstore(rs_slab, voff_slab, (unsigned)((16 + i) * W * sizeof(C)), bb);
+                for (int b = 0; b < NB; ++b) chain_input_pair<T, LOGM, R, ABL>(y0[b], y2[b], rs_sig, 0, 2, L.beta[b], ph);
+                chain_run<T, LOGM, R, NB, ABL>(y0, L, A, rs_spec, 0, pb);
+                chain_run<T, LOGM, R, NB, ABL>(y2, L, A, rs_spec, 2, pb);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const unsigned voff_slab = (unsigned)(L.beta[b] * sizeof(C));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {  // a, b = y0 +- W_64^(2 i) y2'; slab layout [a | b][i][beta]
+                        C a, bb;
+                        bfly_w(y0[b][i], y2[b][i], W64C[2 * i], W64S[2 * i], a, bb);
+                        if constexpr (ABL & 4) { keep(a); keep(bb); continue; }
+                        // One store per value, on purpose.  Packing (a, b) into one 16-byte store per lane was
+                        // tried in complex64: a buffer_store_dwordx4 followed within two wait states by a VALU
+                        // write of its data registers needs an s_nop (CDNA3 ISA 4.5), which the compiler inserts
+                        // for its own instructions but NOT in front of inline asm -- and the packed-f32
+                        // arithmetic here is inline asm (cplx.hpp): 2 % of a surface's lags came out stale.
+                        bstore(rs_slab, voff_slab, (unsigned)(i * W * sizeof(C)), a);
+                        bstore(rs_slab, voff_slab, (unsigned)((16 + i) * W * sizeof(C)), bb);
+                    }
                 }
             }
-            C y1[16], y3[16];
-            chain_run<T, LOGM, R>(y1, L, A, rs_sig, rs_spec, 1, pb, ph);
-            chain_run<T, LOGM, R>(y3, L, A, rs_sig, rs_spec, 3, pb, ph);
+            C y1[NB][16], y3[NB][16];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) chain_input_pair<T, LOGM, R, ABL>(y1[b], y3[b], rs_sig, 1, 3, L.beta[b], ph);
+            chain_run<T, LOGM, R, NB, ABL>(y1, L, A, rs_spec, 1, pb);
+            chain_run<T, LOGM, R, NB, ABL>(y3, L, A, rs_spec, 3, pb);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                // c' , d' = y1' +- W_64^(3i - i) y3' = y1' +- W_64^(2i) y3'   (z_r = W_64^(i r) y'_r)
-                C cc, dd;
-                bfly_w(y1[i], y3[i], W64C[2 * i], W64S[2 * i], cc, dd);
-                const C a = bload(rs_slab, voff_slab, (unsigned)(i * W * sizeof(C)), (C *)nullptr);
-                const C bb = bload(rs_slab, voff_slab, (unsigned)((16 + i) * W * sizeof(C)), (C *)nullptr);
-                C c0, c2, c1, c3;
-                bfly_w(a, cc, W64C[i], W64S[i], c0, c2);              // a +- W_64^i c'
-                bfly_w(bb, dd, -W64S[i], W64C[i], c1, c3);           // b +- i W_64^i d'
-                emit(0, i, c0);
-                emit(1, i, c1);
-                emit(2, i, c2);
-                emit(3, i, c3);
-                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four (a, b) pairs in flight
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const unsigned voff_slab = (unsigned)(L.beta[b] * sizeof(C));
+                    // c' , d' = y1' +- W_64^(2i) y3'   (z_r = W_64^(i r) y'_r)
+                    C cc, dd;
+                    bfly_w(y1[b][i], y3[b][i], W64C[2 * i], W64S[2 * i], cc, dd);
+                    C a, bb;
+                    if constexpr (ABL & 4) {
+                        a = C{T(i), T(1)}; bb = C{T(2), T(i)};
+                        keep(a); keep(bb);
+                    } else {
+                        // sc1: served by L2.  The workgroup rewrites its slab every row, and this CU's vector
+                        // L1 can still hold the line as the PREVIOUS row's read left it (observed: 2 % of a
+                        // surface's lags differed from run to run with plain loads).
+                        a = bload(rs_slab, voff_slab, (unsigned)(i * W * sizeof(C)), (C *)nullptr);
+                        bb = bload(rs_slab, voff_slab, (unsigned)((16 + i) * W * sizeof(C)), (C *)nullptr);
+                    }
+                    C c0, c2, c1, c3;
+                    bfly_w(a, cc, W64C[i], W64S[i], c0, c2);     // a +- W_64^i c'
+                    bfly_w(bb, dd, -W64S[i], W64C[i], c1, c3);  // b +- i W_64^i d'
+                    emit(0, i, b, c0);
+                    emit(1, i, b, c1);
+                    emit(2, i, b, c2);
+                    emit(3, i, b, c3);
+                }
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four (a, b) pairs per slot in flight
             }
         }
         // lags of block j all precede those of block j+1: init (0.0, lag 0) like mod.rs:143
@@ -570,14 +691,17 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W, chain_wps_v(LOGM, sizeof(cpx<T>)
         uint32_t besti = 0u;
 #pragma unroll
         for (int j = 0; j < R; ++j)
-            if (bv[j] > best) { best = bv[j]; besti = (uint32_t)(L.t + W * bi[j] + M * j); }
+            if (bv[j] > best) {
+                best = bv[j];
+                besti = (uint32_t)(L.t + (W / NB) * (bi[j] % NB) + W * (bi[j] / NB) + M * j);
+            }
         wave_arg_reduce_maxmin(best, besti);
         if (lane == 63) { sv[wave] = best; si[wave] = besti; }
         __syncthreads();
         if (L.t == 0) {
             T rb = sv[0];
             uint32_t ri = si[0];
-            for (int w = 1; w < NW; ++w) arg_merge(rb, ri, sv[w], si[w]);
+            for (int w = 1; w < NWV; ++w) arg_merge(rb, ri, sv[w], si[w]);
             A.row_idx[g] = ri;
             A.row_val[g] = rb;
         }

@@ -593,6 +593,26 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t rs, unsigned voff,
     __builtin_amdgcn_raw_buffer_store_b64(caf_v2u{__float_as_uint(x.x), __float_as_uint(x.y)}, rs, voff, soff, 0);
 }
 
+// two ADJACENT complex values per lane: one 16-byte load in complex64, two in complex128.
+// (No store twin on purpose: a 16-byte buffer store whose data registers are rewritten by inline-asm
+// VALU code within two wait states stores garbage -- the compiler's hazard recogniser does not see into
+// inline asm; see the slab stores of kernels_chain.hpp.)
+template <int AUX = 0>
+__device__ __forceinline__ void bload2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, cpx<float> &x0, cpx<float> &x1)
+{
+    const caf_v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX);
+    x0 = {__uint_as_float(r.x), __uint_as_float(r.y)};
+    x1 = {__uint_as_float(r.z), __uint_as_float(r.w)};
+}
+template <int AUX = 0>
+__device__ __forceinline__ void bload2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, cpx<double> &x0, cpx<double> &x1)
+{
+    const caf_v4u r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX);
+    const caf_v4u r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, AUX);
+    x0 = {__longlong_as_double(((long long)r0.y << 32) | r0.x), __longlong_as_double(((long long)r0.w << 32) | r0.z)};
+    x1 = {__longlong_as_double(((long long)r1.y << 32) | r1.x), __longlong_as_double(((long long)r1.w << 32) | r1.z)};
+}
+
 // ---- the row kernel ------------------------------------------------------------------------
 // (f32 at __launch_bounds__(512, 4) -- two workgroups = 4 waves per SIMD -- was measured:
 // 128 VGPRs cost 37 spills and 12 % of throughput.)

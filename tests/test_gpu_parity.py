@@ -517,7 +517,7 @@ def test_L65536_c64_rows(eng, oracle):
     s0, s1, lag, fo = make_pair(n=n, seed=77, lag=173, foffset=12.0, dtype=np.complex64)
     fr = np.array([11.0, 11.5, 12.0, 12.5, 13.0])
     plan = eng.plan(n, fr, FS, dtype="c64")
-    assert plan.path == "chain" and plan.kernel_name == "caf::k_chain_rows<float, 14, 4>"
+    assert plan.path == "chain" and plan.kernel_name == "caf::k_chain_rows<float, 14, 4, 1, 0>"
     plan.close()
     surf, ridx, rval, peak = eng.surface_arrays(s0, s1, fr, FS, dtype="c64")
     osurf, oidx, oval = oracle.np_caf_surface(s0.astype(np.complex128), s1.astype(np.complex128), fr, FS)

@@ -247,11 +247,11 @@ def test_lifetime_rules(eng):
 
 
 # ------------------------------------------ (7) LDS-resident chain path, every covered n --
-CHAIN_CASES = [(1024, "c128", "caf::k_chain_rows<double, 10, 2>"), (2048, "c128", "caf::k_chain_rows<double, 11, 2>"),
-               (8192, "c128", "caf::k_chain_rows<double, 13, 2>"), (16384, "c128", "caf::k_chain_rows<double, 13, 4>"),
-               (1024, "c64", "caf::k_chain_rows<float, 10, 2>"), (2048, "c64", "caf::k_chain_rows<float, 11, 2>"),
-               (8192, "c64", "caf::k_chain_rows<float, 13, 2>"), (16384, "c64", "caf::k_chain_rows<float, 14, 2>"),
-               (32768, "c64", "caf::k_chain_rows<float, 14, 4>")]
+CHAIN_CASES = [(1024, "c128", "caf::k_chain_rows<double, 10, 2, 1, 0>"), (2048, "c128", "caf::k_chain_rows<double, 11, 2, 1, 0>"),
+               (8192, "c128", "caf::k_chain_rows<double, 13, 2, 1, 0>"), (16384, "c128", "caf::k_chain_rows<double, 13, 4, 1, 0>"),
+               (1024, "c64", "caf::k_chain_rows<float, 10, 2, 1, 0>"), (2048, "c64", "caf::k_chain_rows<float, 11, 2, 1, 0>"),
+               (8192, "c64", "caf::k_chain_rows<float, 13, 2, 1, 0>"), (16384, "c64", "caf::k_chain_rows<float, 14, 2, 1, 0>"),
+               (32768, "c64", "caf::k_chain_rows<float, 14, 4, 1, 0>")]
 
 
 @pytest.mark.parametrize("n,dtype,kernel", CHAIN_CASES, ids=lambda v: str(v) if not isinstance(v, str) or len(v) < 6 else None)
@@ -389,3 +389,39 @@ def test_streaming_split_mode_parity(dtype, eng, oracle):
         assert np.max(np.abs(rv.astype(np.float64) - ov)) <= tol * ov.max()
         fb, ib, rib, rvb = results[False][k]
         assert (f, i) == (fb, ib) and np.array_equal(ri, rib) and np.array_equal(rv, rvb)
+
+
+@pytest.mark.parametrize("n,dtype", [(32768, "c64"), (16384, "c128"), (16384, "c64"), (4096, "c128"), (4096, "c64")])
+def test_run_to_run_bit_determinism(n, dtype, eng):
+    """The same launch twice, and the same rows as a shard of another plan, give identical BITS
+    (no atomics on the data path).  Caught in round 2: a 16-byte scratch-slab store whose data
+    registers the following inline-asm arithmetic rewrote two wait states too early (CDNA3 ISA 4.5
+    hazard the compiler does not insert s_nop for in front of inline asm): 2 % of a surface's lags
+    were stale values of the previous row, within every tolerance but different from run to run."""
+    import torch
+    from caf_cookoff_amd.synth import make_pair
+    cdt, tdt = (np.complex128, torch.float64) if dtype == "c128" else (np.complex64, torch.float32)
+    F = 520
+    fr = np.arange(F) * 0.05 - 13.0
+    s0, s1, lag, fo = make_pair(n=n, seed=5, lag=77, foffset=float(fr[300]), dtype=cdt)
+    nd, hs = torch.from_numpy(s0[None]).cuda(), torch.from_numpy(s1[None]).cuda()
+
+    def run(lo, hi):
+        plan = eng.plan(n, fr, FS, dtype=dtype, row_begin=lo, row_end=hi)
+        rows = hi - lo
+        surf = torch.full((1, rows, 2 * n), -1.0, dtype=tdt, device="cuda")
+        ridx = torch.zeros((1, rows), dtype=torch.int64, device="cuda")
+        rval = torch.zeros((1, rows), dtype=tdt, device="cuda")
+        peak = torch.zeros((1, 4), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        plan.surface_dev(nd.data_ptr(), hs.data_ptr(), 1, surf.data_ptr(), ridx.data_ptr(), rval.data_ptr(), peak.data_ptr())
+        eng.synchronize()
+        plan.close()
+        return surf[0], ridx[0], rval[0]
+
+    a = run(0, F)
+    b = run(0, F)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    c = run(100, 400)
+    assert torch.equal(a[0][100:400], c[0]) and torch.equal(a[1][100:400], c[1])
+    assert int(a[1][300]) == lag

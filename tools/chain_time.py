@@ -13,7 +13,8 @@ from caf_cookoff_amd.synth import make_batch  # noqa: E402
 n, F, dtype = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 batch = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 nosurf = len(sys.argv) > 5 and sys.argv[5] == "nosurf"
-eng = caf.Engine(0)
+import os
+eng = caf.Engine(0, lib=caf.MEASURE_LIB_PATH if os.environ.get("CAF_CHAIN_ABL") else None)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 fr = np.linspace(-100.0, 100.0, F, endpoint=False)
 cdt, tdt = (np.complex128, torch.float64) if dtype == "c128" else (np.complex64, torch.float32)
@@ -39,4 +40,4 @@ ok = sum(int(pk[b]["idx"]) == lags[b] for b in range(batch))
 rs = 8 if dtype == "c128" else 4
 out_bytes = batch * F * 2 * n * rs
 print(f"{plan.kernel_name} n={n} F={F} {dtype} batch={batch} surface={'no' if nosurf else 'yes'}: {ms / nl:.4f} ms per launch, "
-      f"{out_bytes / (ms / nl) / 1e6:.0f} GB/s of surface, {batch * F / (ms / nl) * 1e-3:.2f} M rows/s, tau ok {ok}/{batch}")
+      f"{out_bytes / (ms / nl) / 1e6:.0f} GB/s of surface, {batch * F / (ms / nl) * 1e-3:.2f} M rows/s, tau ok {ok}/{batch}" + (f" ABL={os.environ['CAF_CHAIN_ABL']} (wrong results, timing only)" if os.environ.get("CAF_CHAIN_ABL") else ""))
