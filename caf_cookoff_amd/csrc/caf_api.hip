@@ -121,6 +121,9 @@ struct caf_plan {
     DevBuf slab;                             // R = 4: per-workgroup scratch of the last radix-4 stage
     void *slab_override = nullptr;           // streaming slots bring their own
     PeakStageOut stage_out = {nullptr, nullptr, nullptr};  // streaming capture: k_peak also writes the pinned result buffers
+    const void *stage_in_src = nullptr;  // streaming capture, fused path: the spectrum kernel also stages the needles in
+    void *stage_in_dst = nullptr;
+    size_t stage_in_bytes = 0;
     bool bigq = false;          //   ... in its 16 x 4096 two-pass form (kernels_q65536.hpp)
     DevBuf bwork, bhwork, bpart_val, bpart_idx;
     double *d_freqs = nullptr;  // this shard's slice
@@ -674,6 +677,9 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     a.rows = (int)p->rows;
     a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr;
     a.dbg = p->dbg;
+    a.stage_src = (const uint4 *)p->stage_in_src;
+    a.stage_dst = (uint4 *)p->stage_in_dst;
+    a.stage_n16 = (unsigned)(p->stage_in_bytes / 16);
     // haystack spectrum, once per surface (the reference recomputes it per row,
     // xcor_rustfft.rs:58-59)
     a.sig = (const cpx<T> *)d_hay;
@@ -686,7 +692,10 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
 #endif
     {  // one workgroup per (surface, chain): halves the latency of a single-surface call
         const size_t want = 2 * batch, cap2 = 2 * (size_t)c->cu_count;
-        k_seq_prepare<T><<<(unsigned)(want < cap2 ? want : cap2), S_THREADS, 0, c->stream>>>(a, a.phasor);
+        a.fft_blocks = (unsigned)(want < cap2 ? want : cap2);
+        const size_t copy_want = ((size_t)a.stage_n16 + S_THREADS - 1) / S_THREADS;  // streaming slots only
+        const unsigned copy_blocks = (unsigned)(copy_want < 256 ? copy_want : 256);
+        k_seq_prepare<T><<<a.fft_blocks + copy_blocks, S_THREADS, 0, c->stream>>>(a, a.phasor);
     }
     KCHK();
     const size_t total = batch * p->rows;
@@ -1258,6 +1267,7 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     auto bail = [&](int code) {
         c->stream = saved; p->spec_override = nullptr; p->slab_override = nullptr;
         p->stage_out = PeakStageOut{nullptr, nullptr, nullptr};
+        p->stage_in_src = nullptr; p->stage_in_dst = nullptr; p->stage_in_bytes = 0;
         cleanup_aux();
         stream_free(st);
         return code;
@@ -1327,12 +1337,22 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
         p->slab_override = slab;
         p->stage_out = PeakStageOut{(caf_peak *)(m_peak + first * sizeof(caf_peak)), (uint64_t *)(m_ridx + first * ridx1),
                                     (void *)(m_rval + first * rval1)};
-        k_stage_copy<<<(unsigned)(in16 < 1 ? 1 : in16 > 1024 ? 1024 : in16), 256, 0, on>>>(jin);
-        hipError_t e1 = hipGetLastError();
+        hipError_t e1 = hipSuccess;
+        if (p->fused && p->variant != 2 && inb % 16 == 0) {  // the spectrum kernel stages the needles in itself
+            p->stage_in_src = jin.src[0];
+            p->stage_in_dst = jin.dst[0];
+            p->stage_in_bytes = inb;
+        } else {
+            k_stage_copy<<<(unsigned)(in16 < 1 ? 1 : in16 > 1024 ? 1024 : in16), 256, 0, on>>>(jin);
+            e1 = hipGetLastError();
+        }
         int r = caf_surface_dev(p, dn, m_hay + first * in1, nsurf, ds, (uint64_t *)di, dv, (caf_peak *)dp);
         p->spec_override = nullptr;
         p->slab_override = nullptr;
         p->stage_out = PeakStageOut{nullptr, nullptr, nullptr};
+        p->stage_in_src = nullptr;
+        p->stage_in_dst = nullptr;
+        p->stage_in_bytes = 0;
         if (r) return r;
         if (e1 != hipSuccess) return fail(CAF_ERR_HIP, "stage copy launch: %s", hipGetErrorString(e1));
         return CAF_OK;

@@ -338,6 +338,12 @@ struct FusedArgs {
     int total;              // batch*rows (prepare: batch)
     unsigned long long *dbg;  // DIAG builds only: [iter][wave][F_NSTAMP] s_memtime stamps of workgroup 0
     unsigned *work;           // row-ticket counter of this launch (zeroed by the prepare kernel)
+    // streaming slots: the haystack-spectrum kernel also stages the needles from the slot's pinned host
+    // buffer (device mapping) into device memory, 16 bytes per thread and step (no separate copy node)
+    const uint4 *stage_src;
+    uint4 *stage_dst;
+    unsigned stage_n16;
+    unsigned fft_blocks;      // prepare: workgroups [0, fft_blocks) transform, the rest only stage needles in
 };
 
 constexpr int F_NSTAMP = 17;

@@ -199,6 +199,14 @@ __global__ __launch_bounds__(S_THREADS) void k_seq_prepare(const FusedArgs<T> A,
 {
     using C = cpx<T>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[seq_lds_bytes<T>()];
+    // streaming slots: workgroups past the transforming ones only stage the needles in (one 16-byte
+    // read of pinned host memory per thread and step, all in flight together) and leave
+    if (blockIdx.x >= A.fft_blocks) {
+        const unsigned nthr = (gridDim.x - A.fft_blocks) * S_THREADS;
+        for (unsigned i = (blockIdx.x - A.fft_blocks) * S_THREADS + threadIdx.x; i < A.stage_n16; i += nthr)
+            A.stage_dst[i] = A.stage_src[i];
+        return;
+    }
     C *const Lc = reinterpret_cast<C *>(smem);
     C *const twb = Lc + F_CHAIN;
     const SeqLane L;
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(S_THREADS) void k_seq_prepare(const FusedArgs<T> A,
     const C *__restrict__ ph = phasor + (size_t)A.rows * 64;  // the f = 0 row
     const T inv = T(1.0 / 8192.0);
     __syncthreads();
-    for (int w = blockIdx.x; w < 2 * A.total; w += gridDim.x) {
+    for (int w = blockIdx.x; w < 2 * A.total; w += (int)A.fft_blocks) {
         const int b = w >> 1, chain = w & 1;
         const C *sig = A.sig + (size_t)b * F_N;
         C pb = cmul(ph[L.lo4], ph[16 + L.hi4]);
