@@ -38,3 +38,24 @@ def test_product_row_kernels_have_no_vgpr_spills_and_expected_occupancy():
     for name, fields in usage.items():
         if "k_seq_prepare" in name:
             assert int(fields["VGPRs Spill"]) == 0
+
+
+def test_chain_kernels_register_shape():
+    """The size-generic chain kernels (kernels_chain.hpp): LDS per workgroup within 160 KiB, the
+    occupancy the launch code assumes (complex128: 2 waves per SIMD = 256 VGPRs, complex64: 4 = 128
+    VGPRs), and spills bounded -- the R = 2 instantiations run (almost) spill-free since the butterfly
+    constants became SGPR operands; the 1024-thread R = 4 complex64 kernel (BASELINE configs[3]) sits at
+    60-90 spilled registers, a known cost, and must not get worse silently."""
+    usage = _usage()
+    seen = 0
+    for name, f in usage.items():
+        if "k_chain_rows" not in name:
+            continue
+        seen += 1
+        is_f64 = "k_chain_rowsId" in name
+        r4 = "ELi4ELi1ELi0E" in name
+        assert int(f["LDS Size [bytes/block]"]) <= 160 * 1024
+        assert int(f["Occupancy [waves/SIMD]"]) == (2 if is_f64 else 4), name
+        limit = 100 if (r4 and not is_f64) else 30
+        assert int(f["VGPRs Spill"]) <= limit, (name, f["VGPRs Spill"])
+    assert seen == 9  # 4 complex128 + 5 complex64 instantiations
