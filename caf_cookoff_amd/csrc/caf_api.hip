@@ -105,6 +105,11 @@ struct caf_ctx {
     caf_plan *cached = nullptr;
     std::vector<double> cached_freqs;
     std::vector<caf_plan *> plans;  // every live plan of this context (destroyed with it)
+    // Streams of caf_stream slots are pooled per context and reused by later caf_stream objects: how
+    // the runtime spreads streams over its few hardware queues depends on creation order, and a slot
+    // stream that lands on a queue another slot uses serialises the two slots.
+    std::vector<hipStream_t> slot_pool;
+    std::vector<bool> slot_busy;
 };
 
 struct caf_plan {
@@ -250,6 +255,7 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
         if (c->bigwL[d]) (void)hipFree(c->bigwL[d]);
         if (c->qoutw[d]) (void)hipFree(c->qoutw[d]);
     }
+    for (auto st_ : c->slot_pool) (void)hipStreamDestroy(st_);
     for (auto &kv : c->tw_cache) (void)hipFree(kv.second);
     for (auto &kv : c->chain_tabs) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.second); }
     c->io_needle.release(); c->io_hay.release(); c->io_surface.release();
@@ -1219,7 +1225,11 @@ static void stream_free(caf_stream *st)
             if (p) (void)hipHostFree(p);
         for (void *p : {s.d_needle, s.d_surface, s.d_ridx, s.d_rval, s.d_peak, s.d_spec, s.d_slab})
             if (p) (void)hipFree(p);
-        if (s.stream && s.own_stream) (void)hipStreamDestroy(s.stream);
+        if (s.stream && s.own_stream && st->plan) {  // back to the context's pool
+            caf_ctx *c = st->plan->ctx;
+            for (size_t i = 0; i < c->slot_pool.size(); ++i)
+                if (c->slot_pool[i] == s.stream) c->slot_busy[i] = false;
+        }
     }
     if (st->counted && st->plan) --st->plan->live_streams;
     delete st;
@@ -1282,7 +1292,16 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
         // Fused / chain plans: every slot has private device state -> slots run concurrently on
         // their own streams.  tiled65536 / generic plans share the plan's pass workspaces -> one stream.
         if (private_state || si == 0) {
-            SCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            size_t pi = 0;
+            while (pi < c->slot_pool.size() && c->slot_busy[pi]) ++pi;
+            if (pi == c->slot_pool.size()) {
+                hipStream_t ns = nullptr;
+                SCHK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+                c->slot_pool.push_back(ns);
+                c->slot_busy.push_back(false);
+            }
+            c->slot_busy[pi] = true;
+            s.stream = c->slot_pool[pi];
         } else {
             s.stream = st->slots[0].stream;
             s.own_stream = false;
