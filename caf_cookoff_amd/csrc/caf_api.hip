@@ -255,7 +255,8 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
         if (c->bigwL[d]) (void)hipFree(c->bigwL[d]);
         if (c->qoutw[d]) (void)hipFree(c->qoutw[d]);
     }
-    for (auto st_ : c->slot_pool) (void)hipStreamDestroy(st_);
+    for (auto st_ : c->slot_pool)
+        if (st_ != c->own_stream) (void)hipStreamDestroy(st_);
     for (auto &kv : c->tw_cache) (void)hipFree(kv.second);
     for (auto &kv : c->chain_tabs) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.second); }
     c->io_needle.release(); c->io_hay.release(); c->io_surface.release();
@@ -1292,6 +1293,10 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
         // Fused / chain plans: every slot has private device state -> slots run concurrently on
         // their own streams.  tiled65536 / generic plans share the plan's pass workspaces -> one stream.
         if (private_state || si == 0) {
+            if (c->slot_pool.empty()) {  // the context's own stream is the first pooled one: one hardware queue saved
+                c->slot_pool.push_back(c->own_stream);
+                c->slot_busy.push_back(false);
+            }
             size_t pi = 0;
             while (pi < c->slot_pool.size() && c->slot_busy[pi]) ++pi;
             if (pi == c->slot_pool.size()) {
