@@ -109,9 +109,10 @@ def algorithmic_bytes(n_surfaces: int, rows_local: int, n: int, dtype: str) -> i
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the kernel sources: ties a profiles/*/traffic.json to the code it measured."""
+    """sha256 over the kernel sources (csrc/*.hpp: every __global__ function lives there; caf_api.hip is
+    host code): ties a profiles/*/traffic.json to the kernels it measured."""
     h = hashlib.sha256()
-    for f in sorted((ROOT / "caf_cookoff_amd" / "csrc").glob("*.h*")):
+    for f in sorted((ROOT / "caf_cookoff_amd" / "csrc").glob("*.hpp")):
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]

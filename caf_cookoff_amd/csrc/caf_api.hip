@@ -1334,10 +1334,10 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
         evs.resize(batch);
         for (auto &e : evs) { e = nullptr; SCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
     }
-    // One node chain = {stage-in, haystack spectrum, row kernel(s), find_peak, stage-out}: kernels only.
-    // Stage-in / stage-out read / write the slot's pinned host buffers through their device mappings
-    // (k_stage_copy).  Batched slot: ONE chain over `batch` surfaces.  CAF_STREAM_SPLIT: `batch`
-    // single-surface chains in the slot's one graph, as parallel branches when the plan's state is private.
+    // One node chain = {[stage-in,] haystack spectrum, row kernel(s), find_peak}: kernels only, which read
+    // and write the slot's pinned host buffers through their device mappings.  Batched slot: ONE chain
+    // over `batch` surfaces.  CAF_STREAM_SPLIT: `batch` single-surface chains in the slot's one graph, as
+    // parallel branches when the plan's state is private.
     auto chain = [&](StreamSlot &s, hipStream_t on, size_t first, size_t nsurf, void *spec, void *slab) -> int {
         char *m_needle = nullptr, *m_hay = nullptr, *m_peak = nullptr, *m_ridx = nullptr, *m_rval = nullptr;
         HIPCHK(hipHostGetDevicePointer((void **)&m_needle, s.h_needle, 0));
@@ -1350,10 +1350,11 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
         char *dv = (char *)s.d_rval + first * rval1;
         char *ds = s.d_surface ? (char *)s.d_surface + first * surf1 : nullptr;
         const size_t inb = nsurf * in1;
-        // needle: read twice per Doppler row -> staged into device memory by one kernel node;
+        // needle: read twice per Doppler row -> staged into device memory, by extra workgroups of the
+        // haystack-spectrum launch on the fused path (k_seq_prepare), by a k_stage_copy node elsewhere;
         // haystack: read once, by the haystack-spectrum kernel -> that kernel reads the pinned host
-        // buffer in place (no copy node); row peaks + caf_peak: written to the pinned result buffers by
-        // find_peak itself (no stage-out node).  A slot's chain is 4 kernel nodes on the fused path.
+        // buffer in place; row peaks + caf_peak: written to the pinned result buffers by find_peak
+        // itself.  A slot's chain is 3 kernel nodes on the fused path, 4+ on the others.
         CopyJobs jin = {{m_needle + first * in1, nullptr, nullptr}, {dn, nullptr, nullptr}, {inb, 0, 0}};
         const size_t in16 = (inb / 16 + 255) / 256;
         c->stream = on;

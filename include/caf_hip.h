@@ -175,11 +175,13 @@ int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, 
 /* ---- streaming (BASELINE configs[4]) ----------------------------------------------
  * Back-to-back surfaces from host memory: `nslots` (>= 2) independent slots, each with
  * pinned host staging for `batch` (needle, haystack) pairs, its own device buffers, its
- * own HIP stream and ONE captured hipGraph {stage-in of needle + haystack, haystack spectrum,
- * row kernel, find_peak, stage-out of the row peaks + caf_peak records}; stage-in / stage-out
- * are kernel nodes that read / write the pinned buffers through their device mappings (they
- * replay faster than copy-engine nodes).  While slot k computes, the caller fills slot k+1's
- * pinned buffers and submits it: its H2D overlaps slot k's kernels.  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
+ * own HIP stream (from a per-context pool) and ONE captured hipGraph of kernel nodes
+ * {haystack spectrum, row kernel, find_peak}: the kernels read the pinned inputs and write the
+ * pinned results through their device mappings (the haystack is read in place, the needle is
+ * staged into device memory by the spectrum launch, find_peak writes the row peaks and the
+ * caf_peak records out) -- no copy-engine nodes.  While slot k computes, the caller fills slot
+ * k+1's pinned buffers and submits it: its input transfer overlaps slot k's kernels.  Three
+ * slots sustain the most single-surface replays per second on MI355X.  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
  * only (tau, f) + per-row peaks come back, as SURVEY.md section 8d prescribes.
  * Plans whose row kernel keeps its intermediate data on-chip ("fused4096", "chain") give
  * every slot private device state, so slots execute concurrently.  Plans on the "tiled65536"
