@@ -425,3 +425,44 @@ def test_run_to_run_bit_determinism(n, dtype, eng):
     c = run(100, 400)
     assert torch.equal(a[0][100:400], c[0]) and torch.equal(a[1][100:400], c[1])
     assert int(a[1][300]) == lag
+
+
+def test_chain_path_edge_shapes(eng, oracle):
+    """Chain-path plans at the edges of the device API: an empty frequency list, an empty row
+    shard, a single row, and a batch larger than the resident grid's share (rows handed out by
+    stride), complex128 n = 2048 and complex64 n = 1024."""
+    import torch
+    import caf_cookoff_amd as caf
+    rng = np.random.default_rng(9)
+    for n, dtype, cdt, tdt, tol in ((2048, "c128", np.complex128, torch.float64, TOL64), (1024, "c64", np.complex64, torch.float32, TOL32)):
+        a = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cdt)
+        b = (np.roll(a, 11) * np.exp(2j * np.pi * 25.0 * np.arange(n) / FS)).astype(cdt)
+        # empty frequency list through the host API
+        surf, ridx, rval, peak = eng.surface_arrays(a, b, np.array([]), FS, dtype=dtype)
+        assert surf.shape == (0, 2 * n) and (peak.freq, peak.idx, peak.row) == (0.0, 0, -1)
+        # empty shard and single-row shard
+        fr = np.array([0.0, 25.0, 50.0])
+        empty = eng.plan(n, fr, FS, dtype=dtype, row_begin=2, row_end=2)
+        assert empty.path == "chain" and empty.rows == 0
+        empty.close()
+        one = eng.plan(n, fr, FS, dtype=dtype, row_begin=1, row_end=2)
+        batch = 700  # > resident workgroups of any chain kernel on 256 CUs for these sizes? no: exercises the stride loop
+        nd = torch.from_numpy(np.tile(a, (batch, 1))).cuda()
+        hs = torch.from_numpy(np.tile(b, (batch, 1))).cuda()
+        hs[5] = 0  # one all-zero haystack in the batch
+        d_s = torch.empty((batch, 1, 2 * n), dtype=tdt, device="cuda")
+        d_i = torch.empty((batch, 1), dtype=torch.int64, device="cuda")
+        d_v = torch.empty((batch, 1), dtype=tdt, device="cuda")
+        d_p = torch.empty((batch, 4), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        one.surface_dev(nd.data_ptr(), hs.data_ptr(), batch, d_s.data_ptr(), d_i.data_ptr(), d_v.data_ptr(), d_p.data_ptr())
+        eng.synchronize()
+        one.close()
+        osurf, oidx, oval = oracle.np_caf_surface(a.astype(np.complex128), b.astype(np.complex128), fr[1:2], FS)
+        got = d_s.cpu().numpy()
+        assert np.max(np.abs(got[0, 0] - osurf[0])) <= tol * osurf.max()
+        assert np.array_equal(got[0], got[699]) and np.array_equal(got[0], got[350])   # every batch entry identical
+        assert not got[5].any() and int(d_i[5, 0]) == 0
+        pk = d_p.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[:, 0]
+        assert int(pk[0]["idx"]) == 11 and int(pk[0]["row"]) == 1 and int(pk[5]["row"]) == -1
+        assert int(d_i[699, 0]) == 11
