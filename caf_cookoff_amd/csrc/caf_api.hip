@@ -17,7 +17,6 @@
 #include "kernels_fused4096.hpp"
 #include "kernels_seq4096.hpp"
 #include "kernels_duo4096.hpp"
-#include "kernels_big65536.hpp"
 #include "kernels_chain.hpp"
 #include "kernels_generic.hpp"
 // Measurement build (-DCAF_MEASURE -> libcaf_hip_measure.so, used by tools/ and the variant
@@ -26,6 +25,7 @@
 // no environment variable.
 #ifdef CAF_MEASURE
 #include "kernels_r8_4096.hpp"
+#include "kernels_big65536.hpp"  // four-step tiled n = 32768 path of round 1 (CAF_CHAIN=0), superseded by the chain path
 #include "kernels_q65536.hpp"
 #endif
 
@@ -379,8 +379,8 @@ extern "C" int caf_xcor_c64(caf_ctx *c, const float *a, const float *b, size_t n
 // ----------------------------------------------------------- chain path set-up --
 // Which padded lengths the LDS-resident chain kernels (kernels_chain.hpp) cover: L = 2n = R * M
 // with one chain of M points (plus its padding and twiddle tables) inside 160 KiB of LDS:
-//   complex64:  M <= 16384  -> n = 1024, 2048, 8192, 16384 (R = 2), n = 32768 (R = 4, BASELINE configs[3])
-//   complex128: M <=  8192  -> n = 1024, 2048, 8192 (R = 2), n = 16384 (R = 4)
+//   complex64:  M <= 16384  -> n = 1024 ... 16384 (R = 2), 32768 (R = 4, BASELINE configs[3]), 65536 (R = 8)
+//   complex128: M <=  8192  -> n = 1024 ... 8192 (R = 2), 16384 (R = 4), 32768 (R = 8)
 // n = 4096 keeps its tuned kernels (kernels_seq4096.hpp / kernels_duo4096.hpp).
 static bool chain_config(size_t n, int dtype, int *logm, int *R)
 {
@@ -389,6 +389,7 @@ static bool chain_config(size_t n, int dtype, int *logm, int *R)
     size_t M;
     if (n <= m_max) { M = n; *R = 2; }
     else if (n / 2 <= m_max) { M = n / 2; *R = 4; }
+    else if (n / 4 <= m_max) { M = n / 4; *R = 8; }
     else return false;
     int l = 0;
     while (((size_t)1 << l) < M) ++l;
@@ -410,9 +411,11 @@ static bool chain_config(size_t n, int dtype, int *logm, int *R)
         const int logm_ = (logm), R_rt = (R);                                                          \
         if constexpr (sizeof(T) == 4) {                                                                \
             CHAIN_CASE(10, 2, STMT) CHAIN_CASE(11, 2, STMT) CHAIN_CASE(13, 2, STMT) CHAIN_CASE(14, 2, STMT) \
-            CHAIN_CASE(14, 4, STMT) return fail(CAF_ERR_STATE, "chain path: no kernel for M=2^%d R=%d", logm_, R_rt); \
+            CHAIN_CASE(14, 4, STMT) CHAIN_CASE(14, 8, STMT)                                            \
+            return fail(CAF_ERR_STATE, "chain path: no kernel for M=2^%d R=%d", logm_, R_rt);           \
         } else {                                                                                       \
             CHAIN_CASE(10, 2, STMT) CHAIN_CASE(11, 2, STMT) CHAIN_CASE(13, 2, STMT) CHAIN_CASE(13, 4, STMT) \
+            CHAIN_CASE(13, 8, STMT)                                                                    \
             return fail(CAF_ERR_STATE, "chain path: no kernel for M=2^%d R=%d", logm_, R_rt);           \
         }                                                                                              \
     } while (0)
@@ -435,8 +438,9 @@ static int build_chain_tables(caf_plan *p)
     p->c_twM = it->second.first;
     p->c_th = it->second.second;
     const size_t nr = p->rows + 1;  // +1: the f = 0 row for the haystack transform
-    HIPCHK(hipMalloc(&p->d_phasor, nr * CH_PH * sizeof(cpx<T>)));
-    k_chain_phasors<T><<<(unsigned)((nr * CH_PH + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows, M, R,
+    const size_t PH = (size_t)chain_ph_v(R);
+    HIPCHK(hipMalloc(&p->d_phasor, nr * PH * sizeof(cpx<T>)));
+    k_chain_phasors<T><<<(unsigned)((nr * PH + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows, M, R,
                                                                                  (cpx<T> *)p->d_phasor);
     KCHK();
     return CAF_OK;
@@ -466,6 +470,7 @@ static int plan_build_tables(caf_plan *p)
     }
 #endif
     if (p->chain) return build_chain_tables<T>(p);
+#ifdef CAF_MEASURE
     if (p->big) {
         if (!c->bigw256[dt]) {
             HIPCHK(hipMalloc(&c->bigw256[dt], 256 * sizeof(cpx<T>)));
@@ -478,7 +483,10 @@ static int plan_build_tables(caf_plan *p)
         k_big_phasors<T><<<(unsigned)((nr * 384 + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows,
                                                                                    (cpx<T> *)p->d_phasor);
         KCHK();
-    } else if (p->fused) {
+        return CAF_OK;
+    }
+#endif
+    if (p->fused) {
         if ((rc = build_fused_tables<T>(c, dt))) return rc;
         const size_t nr = p->rows + 1;  // +1: the f = 0 row for the haystack transform
         HIPCHK(hipMalloc(&p->d_phasor, nr * 64 * sizeof(cpx<T>)));
@@ -524,7 +532,9 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     p->fused = (n == (size_t)F_N);
     // (CAF_CHAIN=0, measurement build: keep the older tiled65536 / generic paths reachable for comparison)
     p->chain = measure_env("CAF_CHAIN", 1) != 0 && chain_config(n, dtype, &p->clogm, &p->cR);
-    p->big = !p->chain && (n == (size_t)B_N);
+#ifdef CAF_MEASURE
+    p->big = !p->chain && (n == (size_t)B_N);  // only reachable with CAF_CHAIN=0
+#endif
     p->variant = dtype == CAF_C64 ? 3 : 0;  // f32: two chains in flight; f64: sequential chains (kernels_duo4096.hpp)
     // measurement build only: CAF_BIG_PATH=1 = the 16 x 4096 two-pass form (parity-green, 2.63 vs 2.19 ms per
     // 4096-row surface); CAF_ROW_KERNEL = 0..3 picks the n = 4096 row kernel.  No-ops in the product library.
@@ -597,7 +607,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
         return name;
     }
     if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";  // measurement build
-    if (p->big) return f64 ? "caf::k_big_rows<double>" : "caf::k_big_rows<float>";
+    if (p->big) return f64 ? "caf::k_big_rows<double>" : "caf::k_big_rows<float>";  // measurement build
     if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
     if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0, 15>" : "caf::k_seq_rows<float, 0, 0, 15>";
     if (p->variant == 2) return f64 ? "caf::k_r8_rows<double, 0>" : "caf::k_r8_rows<float, 0>";
@@ -870,8 +880,8 @@ static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_ha
     KCHK();
     if (total == 0) return CAF_OK;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
-    if (R == 4) {
-        const size_t slab_bytes = (size_t)cap * 2 * 16 * W * sizeof(cpx<T>);
+    if (R >= 4) {
+        const size_t slab_bytes = (size_t)cap * chain_slab_arrays_v(R) * 16 * W * sizeof(cpx<T>);
         if (!p->slab_override && (rc = p->slab.ensure(slab_bytes))) return rc;
         a.slab = (cpx<T> *)(p->slab_override ? p->slab_override : p->slab.p);
     }
@@ -908,6 +918,7 @@ static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_ha
     return CAF_OK;
 }
 
+#ifdef CAF_MEASURE
 // n = 32768: four-step tiled path (kernels_big65536.hpp)
 template <typename T>
 static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
@@ -976,6 +987,7 @@ static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay,
     if ((rc = timing_mark(p))) return rc;
     return CAF_OK;
 }
+#endif  // CAF_MEASURE
 
 template <typename T>
 static int surface_dev_generic(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch,
@@ -1042,16 +1054,16 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
              : p->chain ? surface_dev_chain<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
 #ifdef CAF_MEASURE
              : p->big && p->bigq ? surface_dev_q<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
-#endif
              : p->big ? surface_dev_big<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+#endif
                       : surface_dev_generic<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     else
         rc = p->fused ? surface_dev_fused<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->chain ? surface_dev_chain<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
 #ifdef CAF_MEASURE
              : p->big && p->bigq ? surface_dev_q<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
-#endif
              : p->big ? surface_dev_big<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+#endif
                       : surface_dev_generic<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     if (rc) return rc;
     // find_peak (mod.rs:31-42)
@@ -1261,9 +1273,9 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     // per-surface spectrum bytes (+256: the fused path's row-ticket word); split branches get one each
     const size_t spec1 = p->fused ? (size_t)2 * 16 * 256 * esz : p->chain ? p->L * esz : 0;
     const size_t spec_stride = split ? spec1 + 256 : 0;
-    const size_t slab1 = p->chain && p->cR == 4
-                             ? (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, esz, chain_nb_v(p->clogm, esz)) * 2 * 16 *
-                                   (((size_t)1 << p->clogm) / 16) * esz
+    const size_t slab1 = p->chain && p->cR >= 4
+                             ? (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, esz, chain_nb_v(p->clogm, esz)) *
+                                   chain_slab_arrays_v(p->cR) * 16 * (((size_t)1 << p->clogm) / 16) * esz
                              : 0;
     hipStream_t saved = c->stream;
     std::vector<hipStream_t> aux;   // capture-time fork streams of the split mode

@@ -2,13 +2,13 @@
 //
 // Same mathematics as kernels_seq4096.hpp (mod.rs:121-166 with FFT(haystack) hoisted and every
 // transform a positive-exponent one), for any padded length L = 2n = R * M that splits into
-// R in {2, 4} "chains" of M = 2^LOGM points, M * sizeof(complex) <= ~128 KiB so ONE chain lives
+// R in {2, 4, 8} "chains" of M = 2^LOGM points, M * sizeof(complex) <= ~128 KiB so ONE chain lives
 // in a workgroup's LDS:
 //
 //   forward, decimation in frequency over the first radix-R stage: bins k = R k' + r,
 //     G[R k' + r] = IDFT_M(u_r)[k'],  u_r[n'] = W_L^(n' r) * sum_{j < R/2} conj(s[n' + M j]) W_R^(j r)
 //     (the upper half of s = needle * w^n ++ 0 is the zero padding of mod.rs:130, so only R/2
-//     of the R terms exist: R = 2 -> one, R = 4 -> two);
+//     of the R terms exist: R = 2 -> one, R = 4 -> two, R = 8 -> four);
 //   product with the pre-permuted haystack spectrum Hs = FFT_L(haystack ++ 0)/L in registers
 //     (xcor_rustfft.rs:64-73);
 //   inverse, decimation in time: y_r = IDFT_M(Hs G restricted to chain r), natural order, and the
@@ -32,8 +32,10 @@
 // chain outputs of a lag, 64 complex per thread -- more than the register file holds at this
 // occupancy -- so a = y0 + W y2 and b = y0 - W y2 go to a per-workgroup scratch slab in global
 // memory (32 complex per thread, written and read back by the SAME thread: no synchronisation,
-// L2-resident) while chains 1 and 3 run.  Traffic per row: the surface once + that slab once
-// each way, instead of three passes over a work row (kernels_big65536.hpp).
+// served by L2 / the Infinity Cache) while chains 1 and 3 run.  Traffic per row: the surface once +
+// that slab once each way, instead of three passes over a work row (kernels_big65536.hpp).
+// R = 8 (n = 65536 complex64, n = 32768 complex128): the same with chain pairs (r', r'+4) and two
+// radix-4 combinations at the end; six slab arrays.
 #pragma once
 #include "kernels_seq4096.hpp"
 
@@ -79,6 +81,8 @@ constexpr size_t chain_wg_per_cu_v(int logm, size_t csize, int nb = 1)
     if (per_cu * waves_wg > (size_t)chain_wps_v(logm, csize, nb) * 4) per_cu = (size_t)chain_wps_v(logm, csize, nb) * 4 / waves_wg;
     return per_cu < 1 ? 1 : per_cu;
 }
+// scratch-slab arrays per workgroup: R = 4: a, b;  R = 8: P0/aP, Q0/bP, aQ, bQ, P1, Q1
+constexpr int chain_slab_arrays_v(int R) { return R == 8 ? 6 : 2; }
 // butterflies per thread of the row kernel (see ChainLane: two was measured and lost)
 constexpr int chain_nb_v(int, size_t) { return 1; }
 template <typename T, int LOGM>
@@ -100,18 +104,21 @@ __global__ void k_chain_tables(cpx<T> *__restrict__ twM, cpx<T> *__restrict__ th
     }
 }
 
-// Per-row phasor table, CH_PH entries per row (row `nrows` = the f = 0 row for the haystack):
+// Per-row phasor table, chain_ph_v(R) entries per row (row `nrows` = the f = 0 row for the haystack):
 //   [0..15] w^j   [16..31] w^(16 j)   [32..47] w^(256 j)
 //   [48 + 16 r + q] step_r[q] = w^(W q) * e^{-2 pi i q r / (16 R)}      (r < R, q < 16)
-//   [112] w^M                                                          (R = 4: second half of the needle)
+//   R = 4: [112] w^M                              (second half of the needle)
+//   R = 8: [176 + 3 r' + (j-1)] kappa_{r',j} = w^(M j) * e^{-2 pi i j r' / 8}, r' < 4, j = 1..3
+//          (quarters 1..3 of the needle, with the pruned radix-8 input stage's constants folded in)
 // every entry from one f64 sincos of the exact phase product (never an f32
 // recurrence), w = e^{j ph}, ph = ((2 PI) f)(1/fs) as mod.rs:54-56.
-constexpr int CH_PH = 128;
+constexpr int chain_ph_v(int R) { return R == 8 ? 256 : 128; }
 template <typename T>
 __global__ void k_chain_phasors(const double *__restrict__ ph, int nrows, int M, int R, cpx<T> *__restrict__ tab)
 {
+    const int PH = chain_ph_v(R);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = g / CH_PH, e = g % CH_PH;
+    const int row = g / PH, e = g % PH;
     if (row > nrows) return;
     const double p = row < nrows ? ph[row] : 0.0;
     const int W = M / 16;
@@ -119,15 +126,20 @@ __global__ void k_chain_phasors(const double *__restrict__ ph, int nrows, int M,
     if (e < 16) mult = (double)e;
     else if (e < 32) mult = 16.0 * (double)(e - 16);
     else if (e < 48) mult = 256.0 * (double)(e - 32);
-    else if (e < 112) {
+    else if (e < 48 + 16 * R) {
         const int r = (e - 48) >> 4, q = (e - 48) & 15;
         mult = (double)W * (double)q;
         rot = (double)(q * r) / (16.0 * (double)R);
-    } else if (e == 112) mult = (double)M;
+    } else if (R == 4 && e == 112) mult = (double)M;
+    else if (R == 8 && e >= 176 && e < 188) {
+        const int rp = (e - 176) / 3, j = (e - 176) % 3 + 1;
+        mult = (double)M * (double)j;
+        rot = (double)(j * rp) / 8.0;
+    }
     double s, c, s2, c2;
     sincos(p * mult, &s, &c);
     sincospi(-2.0 * rot, &s2, &c2);
-    tab[(size_t)row * CH_PH + e] = {(T)(c * c2 - s * s2), (T)(c * s2 + s * c2)};
+    tab[(size_t)row * PH + e] = {(T)(c * c2 - s * s2), (T)(c * s2 + s * c2)};
 }
 
 template <typename T>
@@ -139,7 +151,7 @@ struct ChainArgs {
     T *surface;             // [batch][rows][L] or nullptr
     uint64_t *row_idx;      // [batch][rows]
     T *row_val;             // [batch][rows]
-    cpx<T> *slab;           // R = 4: [gridDim.x][2][16][W] scratch (a, b of the last radix-4 stage)
+    cpx<T> *slab;           // R >= 4: [gridDim.x][chain_slab_arrays_v(R)][16][W] scratch of the last radix-R stage
     int rows;               // rows per surface handled by this plan
     int total;              // batch*rows (prepare: batch)
 };
@@ -401,25 +413,31 @@ __device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[
 {
     using C = cpx<T>;
     constexpr int W = ChainGeo<LOGM>::W, M = ChainGeo<LOGM>::M;
-    constexpr int GQ = (R == 4 && sizeof(T) == 4) ? 2 : 4;  // register rows per fetch group (two groups in flight)
+    constexpr int NQ = R / 2;                                   // nonzero quarters / halves of the padded needle
+    constexpr int GQ = (R == 2) ? 4 : (sizeof(T) == 4 ? 2 : 4);  // register rows per fetch group (two groups in flight)
     const C *psA = ph + 48 + 16 * rA, *psB = ph + 48 + 16 * rB;
     const unsigned voff = (unsigned)(beta * sizeof(C));
-    C wM = C{T(1), T(0)};
-    if constexpr (R == 4) wM = ph[112];
-    C a0[2][GQ], a1[2][GQ];
+    C k1 = C{T(1), T(0)}, k2 = k1, k3 = k1;
+    if constexpr (R == 4) k1 = ph[112];  // w^M
+    if constexpr (R == 8) {              // kappa_{rA, 1..3}
+        k1 = ph[176 + 3 * rA];
+        k2 = ph[176 + 3 * rA + 1];
+        k3 = ph[176 + 3 * rA + 2];
+    }
+    C a[2][GQ][NQ];
     auto fetch = [&](int grp) {
 #pragma unroll
         for (int u = 0; u < GQ; ++u) {
             const int q = GQ * grp + u;
-            if constexpr (ABL & 8) {
-                a0[grp & 1][u] = C{T(q + 1), T(beta)};
-                a1[grp & 1][u] = C{T(beta), T(q)};
-                keep(a0[grp & 1][u]);
-                keep(a1[grp & 1][u]);
-                continue;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if constexpr (ABL & 8) {
+                    a[grp & 1][u][j] = C{T(q + 1 + j), T(beta)};
+                    keep(a[grp & 1][u][j]);
+                    continue;
+                }
+                a[grp & 1][u][j] = bload(rs_sig, voff, (unsigned)((M * j + W * q) * sizeof(C)), (C *)nullptr);
             }
-            a0[grp & 1][u] = bload(rs_sig, voff, (unsigned)(W * q * sizeof(C)), (C *)nullptr);
-            if constexpr (R == 4) a1[grp & 1][u] = bload(rs_sig, voff, (unsigned)((M + W * q) * sizeof(C)), (C *)nullptr);
         }
     };
     fetch(0);
@@ -429,15 +447,21 @@ __device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[
 #pragma unroll
         for (int u = 0; u < GQ; ++u) {
             const int q = GQ * grp + u;
-            const C x = a0[grp & 1][u];
-            if constexpr (R == 4) {
-                const C b = cmul(a1[grp & 1][u], wM);
+            const C x = a[grp & 1][u][0];
+            if constexpr (R == 2) {
+                vA[q] = cmul_conj(x, psA[q]);
+                vB[q] = cmul_conj(x, psB[q]);
+            } else if constexpr (R == 4) {
+                const C b = cmul(a[grp & 1][u][1], k1);
                 // rA = 0: x +- b;  rA = 1: x -+ i b
                 vA[q] = cmul_conj(rA == 0 ? x + b : sub_i(x, b), psA[q]);
                 vB[q] = cmul_conj(rA == 0 ? x - b : add_i(x, b), psB[q]);
             } else {
-                vA[q] = cmul_conj(x, psA[q]);
-                vB[q] = cmul_conj(x, psB[q]);
+                // x_rA = E + O, x_(rA+4) = E - O;  E = a0 + kappa_2 a2,  O = kappa_1 a1 + kappa_3 a3
+                const C E = cfma(x, a[grp & 1][u][2], k2);
+                const C O = cfma(cmul(a[grp & 1][u][1], k1), a[grp & 1][u][3], k3);
+                vA[q] = cmul_conj(E + O, psA[q]);
+                vB[q] = cmul_conj(E - O, psB[q]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -463,8 +487,12 @@ __device__ constexpr double W64S[32] = {
     0.83146961230254523708, 0.77301045336273696081, 0.70710678118654752440, 0.63439328416364549822,
     0.55557023301960222474, 0.47139673682599764856, 0.38268343236508977173, 0.29028467725446236764,
     0.19509032201612826785, 0.09801714032956060199};
+// e^{2 pi i k / 128}, k < 64 (last radix-8 stage: L / W = 128)
+__device__ constexpr double W128C[64] = {1.00000000000000000000, 0.99879545620517240501, 0.99518472667219692873, 0.98917650996478101444, 0.98078528040323043058, 0.97003125319454397424, 0.95694033573220882438, 0.94154406518302080631, 0.92387953251128673848, 0.90398929312344333820, 0.88192126434835504956, 0.85772861000027211809, 0.83146961230254523567, 0.80320753148064494287, 0.77301045336273699338, 0.74095112535495910588, 0.70710678118654757274, 0.67155895484701833009, 0.63439328416364548779, 0.59569930449243346793, 0.55557023301960228867, 0.51410274419322166128, 0.47139673682599780857, 0.42755509343028219593, 0.38268343236508983729, 0.33688985339222005111, 0.29028467725446233105, 0.24298017990326398197, 0.19509032201612833135, 0.14673047445536174793, 0.09801714032956077016, 0.04906767432741812596, 0.0, -0.04906767432741800800, -0.09801714032956064526, -0.14673047445536163691, -0.19509032201612819257, -0.24298017990326387094, -0.29028467725446216452, -0.33688985339221994009, -0.38268343236508972627, -0.42755509343028186287, -0.47139673682599769755, -0.51410274419322166128, -0.55557023301960195560, -0.59569930449243335691, -0.63439328416364537677, -0.67155895484701844111, -0.70710678118654746172, -0.74095112535495888384, -0.77301045336273699338, -0.80320753148064483184, -0.83146961230254534669, -0.85772861000027200706, -0.88192126434835493853, -0.90398929312344333820, -0.92387953251128673848, -0.94154406518302069529, -0.95694033573220882438, -0.97003125319454397424, -0.98078528040323043058, -0.98917650996478101444, -0.99518472667219681771, -0.99879545620517240501};
+__device__ constexpr double W128S[64] = {0.00000000000000000000, 0.04906767432741801493, 0.09801714032956060363, 0.14673047445536174793, 0.19509032201612824808, 0.24298017990326387094, 0.29028467725446233105, 0.33688985339222005111, 0.38268343236508978178, 0.42755509343028208491, 0.47139673682599764204, 0.51410274419322166128, 0.55557023301960217765, 0.59569930449243335691, 0.63439328416364548779, 0.67155895484701833009, 0.70710678118654746172, 0.74095112535495910588, 0.77301045336273699338, 0.80320753148064483184, 0.83146961230254523567, 0.85772861000027211809, 0.88192126434835493853, 0.90398929312344333820, 0.92387953251128673848, 0.94154406518302080631, 0.95694033573220893540, 0.97003125319454397424, 0.98078528040323043058, 0.98917650996478101444, 0.99518472667219681771, 0.99879545620517240501, 1.00000000000000000000, 0.99879545620517240501, 0.99518472667219692873, 0.98917650996478101444, 0.98078528040323043058, 0.97003125319454397424, 0.95694033573220893540, 0.94154406518302080631, 0.92387953251128673848, 0.90398929312344344922, 0.88192126434835504956, 0.85772861000027211809, 0.83146961230254545772, 0.80320753148064494287, 0.77301045336273710440, 0.74095112535495899486, 0.70710678118654757274, 0.67155895484701855214, 0.63439328416364548779, 0.59569930449243346793, 0.55557023301960217765, 0.51410274419322177231, 0.47139673682599786408, 0.42755509343028202940, 0.38268343236508989280, 0.33688985339222032867, 0.29028467725446238656, 0.24298017990326406523, 0.19509032201612860891, 0.14673047445536180344, 0.09801714032956082567, 0.04906767432741796636};
 
-// chain input of ONE chain (the haystack transform; not on the row path)
+
+// chain input of ONE chain (the haystack transform; not on the row path): w = 1
 template <typename T, int LOGM, int R>
 __device__ __forceinline__ void chain_input_one(cpx<T> (&v)[16], const __amdgpu_buffer_rsrc_t rs_sig, int r, int beta,
                                                 const cpx<T> *__restrict__ ph)
@@ -480,6 +508,15 @@ __device__ __forceinline__ void chain_input_one(cpx<T> (&v)[16], const __amdgpu_
             const C b = bload(rs_sig, voff, (unsigned)((M + W * q) * sizeof(C)), (C *)nullptr);  // w = 1: wM = 1
             x = r == 0 ? x + b : r == 1 ? sub_i(x, b) : r == 2 ? x - b : add_i(x, b);
         }
+        if constexpr (R == 8) {  // the f = 0 row's kappa_{r', j} = e^{-2 pi i j r'/8}; chains r'+4 take E - O
+            const int rp = r & 3;
+            const C a1 = bload(rs_sig, voff, (unsigned)((M + W * q) * sizeof(C)), (C *)nullptr);
+            const C a2 = bload(rs_sig, voff, (unsigned)((2 * M + W * q) * sizeof(C)), (C *)nullptr);
+            const C a3 = bload(rs_sig, voff, (unsigned)((3 * M + W * q) * sizeof(C)), (C *)nullptr);
+            const C E = cfma(x, a2, ph[176 + 3 * rp + 1]);
+            const C O = cfma(cmul(a1, ph[176 + 3 * rp]), a3, ph[176 + 3 * rp + 2]);
+            x = r < 4 ? E + O : E - O;
+        }
         v[q] = cmul_conj(x, ps[q]);
     }
 }
@@ -494,7 +531,7 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W) void k_chain_prepare(const Chain
     __shared__ __attribute__((aligned(16))) unsigned char smem[chain_lds_bytes<T, LOGM>()];
     const ChainLane<T, LOGM, 1> L(smem, A.twM);
     constexpr int NS_IN = R * G::M / 2;  // samples per input
-    const C *__restrict__ ph = phasor + (size_t)A.rows * CH_PH;  // the f = 0 row
+    const C *__restrict__ ph = phasor + (size_t)A.rows * chain_ph_v(R);  // the f = 0 row
     const T inv = T(1.0 / (double)(R * G::M));
     __syncthreads();
     for (int w = blockIdx.x; w < R * A.total; w += gridDim.x) {
@@ -579,7 +616,7 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cp
         // descriptor built from a VGPR value costs a waterfall loop per load)
         const int bs = __builtin_amdgcn_readfirstlane(g / A.rows);
         const int r_row = __builtin_amdgcn_readfirstlane(g - bs * A.rows);
-        const C *__restrict__ ph = phasor + (size_t)r_row * CH_PH;
+        const C *__restrict__ ph = phasor + (size_t)r_row * chain_ph_v(R);
         const __amdgpu_buffer_rsrc_t rs_sig = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.sig + (size_t)bs * NS_IN), 0, NS_IN * (int)sizeof(C), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(
@@ -624,66 +661,125 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cp
             }
         } else {
             // this workgroup's scratch slab through a buffer descriptor: per-lane byte offset in one VGPR,
-            // the register-row offset in an SGPR (32 separate 64-bit global addresses would cost 64 VGPRs)
+            // the register-row offset in an SGPR (32 separate 64-bit global addresses would cost 64 VGPRs).
+            // One access per value, on purpose.  Packing two values into one 16-byte store per lane was
+            // tried in complex64: a buffer_store_dwordx4 followed within two wait states by a VALU write of
+            // its data registers needs an s_nop (CDNA3 ISA 4.5), which the compiler inserts for its own
+            // instructions but NOT in front of inline asm -- and the packed-f32 arithmetic here is inline
+            // asm (cplx.hpp): 2 % of a surface's lags came out as the previous row's values.
+            constexpr int NARR = chain_slab_arrays_v(R);
             const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(A.slab + (size_t)blockIdx.x * (2 * 16 * W)), 0, 2 * 16 * W * (int)sizeof(C), 0x00020000);
-            {
-                C y0[NB][16], y2[NB][16];
+                (void *)(A.slab + (size_t)blockIdx.x * (NARR * 16 * W)), 0, NARR * 16 * W * (int)sizeof(C), 0x00020000);
+            auto slab_st = [&](int arr, int i, int b, C x) {
+                if constexpr (ABL & 4) { keep(x); return; }
+                bstore(rs_slab, (unsigned)(L.beta[b] * sizeof(C)), (unsigned)((arr * 16 + i) * W * sizeof(C)), x);
+            };
+            auto slab_ld = [&](int arr, int i, int b) -> C {
+                if constexpr (ABL & 4) { C x = C{T(i), T(arr)}; keep(x); return x; }
+                return bload(rs_slab, (unsigned)(L.beta[b] * sizeof(C)), (unsigned)((arr * 16 + i) * W * sizeof(C)), (C *)nullptr);
+            };
+            if constexpr (R == 4) {
+                // z_r = W_64^(i r) y'_r;  a, b = z0 +- z2;  c, d = z1 +- z3 = W_64^i (y1' +- W_64^(2i) y3');
+                // c[m' + M j]: j = 0, 2: a +- c;  j = 1, 3: b +- i d
+                {
+                    C y0[NB][16], y2[NB][16];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) chain_input_pair<T, LOGM, R, ABL>(y0[b], y2[b], rs_sig, 0, 2, L.beta[b], ph);
-                chain_run<T, LOGM, R, NB, ABL>(y0, L, A, rs_spec, 0, pb);
-                chain_run<T, LOGM, R, NB, ABL>(y2, L, A, rs_spec, 2, pb);
+                    for (int b = 0; b < NB; ++b) chain_input_pair<T, LOGM, R, ABL>(y0[b], y2[b], rs_sig, 0, 2, L.beta[b], ph);
+                    chain_run<T, LOGM, R, NB, ABL>(y0, L, A, rs_spec, 0, pb);
+                    chain_run<T, LOGM, R, NB, ABL>(y2, L, A, rs_spec, 2, pb);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const unsigned voff_slab = (unsigned)(L.beta[b] * sizeof(C));
+                    for (int b = 0; b < NB; ++b) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {  // a, b = y0 +- W_64^(2 i) y2'; slab layout [a | b][i][beta]
-                        C a, bb;
-                        bfly_w(y0[b][i], y2[b][i], W64C[2 * i], W64S[2 * i], a, bb);
-                        if constexpr (ABL & 4) { keep(a); keep(bb); continue; }
-                        // One store per value, on purpose.  Packing (a, b) into one 16-byte store per lane was
-                        // tried in complex64: a buffer_store_dwordx4 followed within two wait states by a VALU
-                        // write of its data registers needs an s_nop (CDNA3 ISA 4.5), which the compiler inserts
-                        // for its own instructions but NOT in front of inline asm -- and the packed-f32
-                        // arithmetic here is inline asm (cplx.hpp): 2 % of a surface's lags came out stale.
-                        bstore(rs_slab, voff_slab, (unsigned)(i * W * sizeof(C)), a);
-                        bstore(rs_slab, voff_slab, (unsigned)((16 + i) * W * sizeof(C)), bb);
+                        for (int i = 0; i < 16; ++i) {
+                            C a, bb;
+                            bfly_w(y0[b][i], y2[b][i], W64C[2 * i], W64S[2 * i], a, bb);
+                            slab_st(0, i, b, a);
+                            slab_st(1, i, b, bb);
+                        }
                     }
                 }
-            }
-            C y1[NB][16], y3[NB][16];
+                C y1[NB][16], y3[NB][16];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) chain_input_pair<T, LOGM, R, ABL>(y1[b], y3[b], rs_sig, 1, 3, L.beta[b], ph);
-            chain_run<T, LOGM, R, NB, ABL>(y1, L, A, rs_spec, 1, pb);
-            chain_run<T, LOGM, R, NB, ABL>(y3, L, A, rs_spec, 3, pb);
+                for (int b = 0; b < NB; ++b) chain_input_pair<T, LOGM, R, ABL>(y1[b], y3[b], rs_sig, 1, 3, L.beta[b], ph);
+                chain_run<T, LOGM, R, NB, ABL>(y1, L, A, rs_spec, 1, pb);
+                chain_run<T, LOGM, R, NB, ABL>(y3, L, A, rs_spec, 3, pb);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+                for (int i = 0; i < 16; ++i) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const unsigned voff_slab = (unsigned)(L.beta[b] * sizeof(C));
-                    // c' , d' = y1' +- W_64^(2i) y3'   (z_r = W_64^(i r) y'_r)
-                    C cc, dd;
-                    bfly_w(y1[b][i], y3[b][i], W64C[2 * i], W64S[2 * i], cc, dd);
-                    C a, bb;
-                    if constexpr (ABL & 4) {
-                        a = C{T(i), T(1)}; bb = C{T(2), T(i)};
-                        keep(a); keep(bb);
-                    } else {
-                        // sc1: served by L2.  The workgroup rewrites its slab every row, and this CU's vector
-                        // L1 can still hold the line as the PREVIOUS row's read left it (observed: 2 % of a
-                        // surface's lags differed from run to run with plain loads).
-                        a = bload(rs_slab, voff_slab, (unsigned)(i * W * sizeof(C)), (C *)nullptr);
-                        bb = bload(rs_slab, voff_slab, (unsigned)((16 + i) * W * sizeof(C)), (C *)nullptr);
+                    for (int b = 0; b < NB; ++b) {
+                        C cc, dd;
+                        bfly_w(y1[b][i], y3[b][i], W64C[2 * i], W64S[2 * i], cc, dd);
+                        const C a = slab_ld(0, i, b), bb = slab_ld(1, i, b);
+                        C c0, c2, c1, c3;
+                        bfly_w(a, cc, W64C[i], W64S[i], c0, c2);     // a +- W_64^i c'
+                        bfly_w(bb, dd, -W64S[i], W64C[i], c1, c3);  // b +- i W_64^i d'
+                        emit(0, i, b, c0);
+                        emit(1, i, b, c1);
+                        emit(2, i, b, c2);
+                        emit(3, i, b, c3);
                     }
-                    C c0, c2, c1, c3;
-                    bfly_w(a, cc, W64C[i], W64S[i], c0, c2);     // a +- W_64^i c'
-                    bfly_w(bb, dd, -W64S[i], W64C[i], c1, c3);  // b +- i W_64^i d'
-                    emit(0, i, b, c0);
-                    emit(1, i, b, c1);
-                    emit(2, i, b, c2);
-                    emit(3, i, b, c3);
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four (a, b) pairs per slot in flight
                 }
-                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four (a, b) pairs per slot in flight
+            } else {
+                // R = 8.  z_r = W_128^(i r) y'_r.  Pairs (r', r'+4): P_r' = y'_r' + W_32^i y'_(r'+4), Q_r' = y'_r' - ...;
+                // lags m' + M j:  j = 2j'   : sum_r' (i)^(j' r') thP^r' P_r',  thP = W_128^i
+                //                 j = 2j'+1 : sum_r' (i)^(j' r') thQ^r' Q_r',  thQ = W_128^(i+16)
+                // i.e. two radix-4 combinations like the R = 4 one.  Pair order 0, 2, 1, 3; slab arrays:
+                // [0],[1] = P0, Q0 -> aP, bP;  [2],[3] = aQ, bQ;  [4],[5] = P1, Q1;  P3, Q3 stay in registers.
+                static_assert(NB == 1, "R = 8 is written for one butterfly per thread");
+                C u[1][16], v[1][16];
+                auto run_pair = [&](int rp) {
+                    chain_input_pair<T, LOGM, R, ABL>(u[0], v[0], rs_sig, rp, rp + 4, L.beta[0], ph);
+                    chain_run<T, LOGM, R, NB, ABL>(u, L, A, rs_spec, rp, pb);
+                    chain_run<T, LOGM, R, NB, ABL>(v, L, A, rs_spec, rp + 4, pb);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {  // P, Q in place of y'_r', y'_(r'+4)
+                        C P, Q;
+                        bfly_w(u[0][i], v[0][i], W32C16[i], W32S16[i], P, Q);
+                        u[0][i] = P;
+                        v[0][i] = Q;
+                    }
+                };
+                run_pair(0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { slab_st(0, i, 0, u[0][i]); slab_st(1, i, 0, v[0][i]); }
+                run_pair(2);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {  // a, b = X0 +- theta^2 X2
+                    C aP, bP, aQ, bQ;
+                    bfly_w(slab_ld(0, i, 0), u[0][i], W128C[2 * i], W128S[2 * i], aP, bP);
+                    bfly_w(slab_ld(1, i, 0), v[0][i], W128C[2 * i + 32], W128S[2 * i + 32], aQ, bQ);
+                    slab_st(0, i, 0, aP);
+                    slab_st(1, i, 0, bP);
+                    slab_st(2, i, 0, aQ);
+                    slab_st(3, i, 0, bQ);
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                run_pair(1);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { slab_st(4, i, 0, u[0][i]); slab_st(5, i, 0, v[0][i]); }
+                run_pair(3);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    C cc, dd, o0, o1, o2, o3;
+                    // even lag blocks: theta = W_128^i
+                    bfly_w(slab_ld(4, i, 0), u[0][i], W128C[2 * i], W128S[2 * i], cc, dd);   // c', d' = P1 +- theta^2 P3
+                    bfly_w(slab_ld(0, i, 0), cc, W128C[i], W128S[i], o0, o2);               // aP +- theta c'
+                    bfly_w(slab_ld(1, i, 0), dd, -W128S[i], W128C[i], o1, o3);              // bP +- i theta d'
+                    emit(0, i, 0, o0);
+                    emit(2, i, 0, o1);
+                    emit(4, i, 0, o2);
+                    emit(6, i, 0, o3);
+                    // odd lag blocks: theta = W_128^(i+16)
+                    bfly_w(slab_ld(5, i, 0), v[0][i], W128C[2 * i + 32], W128S[2 * i + 32], cc, dd);
+                    bfly_w(slab_ld(2, i, 0), cc, W128C[i + 16], W128S[i + 16], o0, o2);
+                    bfly_w(slab_ld(3, i, 0), dd, -W128S[i + 16], W128C[i + 16], o1, o3);
+                    emit(1, i, 0, o0);
+                    emit(3, i, 0, o1);
+                    emit(5, i, 0, o2);
+                    emit(7, i, 0, o3);
+                    if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // at most two rows of slab values in flight
+                }
             }
         }
         // lags of block j all precede those of block j+1: init (0.0, lag 0) like mod.rs:143

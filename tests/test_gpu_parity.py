@@ -528,8 +528,8 @@ def test_L65536_c64_rows(eng, oracle):
     print(f"L=65536 c64: max|d|/max = {np.max(np.abs(surf - osurf)) / osurf.max():.3e}")
 
 
-def test_L65536_c128_tiled_path_and_negative_lag(eng, oracle):
-    """Same geometry in complex128 (tolerance 1e-6 of max), needle delayed w.r.t. the haystack
+def test_L65536_c128_chain_path_and_negative_lag(eng, oracle):
+    """Same geometry in complex128 (chain path, 8 chains of 8192 points) (tolerance 1e-6 of max), needle delayed w.r.t. the haystack
     (negative lag -> index >= n), all-zero input, and a 2-surface batch through the plan."""
     import torch
     import caf_cookoff_amd as caf
@@ -598,21 +598,24 @@ def _plan_arrays_n(plan, eng, nd, hs, dtype, n):
     return surf[0].cpu().numpy().astype(np.float64), ridx[0].cpu().numpy(), rval[0].cpu().numpy(), pk
 
 
-def test_tiled65536_c64_via_measurement_build(meng, oracle, monkeypatch):
-    """The four-step tiled path in complex64 (the product's n = 32768 complex64 plans moved to the
-    chain path in round 2; complex128 still uses it): reachable through the measurement library
-    with CAF_CHAIN=0, and still parity-green."""
+@pytest.mark.parametrize("dtype", ["c64", "c128"])
+def test_tiled65536_via_measurement_build(meng, oracle, monkeypatch, dtype):
+    """The four-step tiled path of round 1 (kernels_big65536.hpp): the product's n = 32768 plans moved
+    to the chain path in round 2 (complex64 as 4 x 16384, complex128 as 8 x 8192), so the tiled form
+    lives in the measurement library only, behind CAF_CHAIN=0 -- kept as the A/B partner of the chain
+    kernels, and still parity-green."""
     from caf_cookoff_amd.synth import make_pair
     monkeypatch.setenv("CAF_CHAIN", "0")
     n = 32768
-    s0, s1, lag, fo = make_pair(n=n, seed=77, lag=173, foffset=12.0, dtype=np.complex64)
+    cdt, tol = (np.complex64, TOL32) if dtype == "c64" else (np.complex128, TOL64)
+    s0, s1, lag, fo = make_pair(n=n, seed=77, lag=173, foffset=12.0, dtype=cdt)
     fr = np.array([11.5, 12.0, 12.5])
-    plan = meng.plan(n, fr, FS, dtype="c64")
-    assert plan.path == "tiled65536"
-    surf, ridx, rval, pk = _plan_arrays_n(plan, meng, s0, s1, "c64", n)
+    plan = meng.plan(n, fr, FS, dtype=dtype)
+    assert plan.path == "tiled65536" and "k_big_rows" in plan.kernel_name
+    surf, ridx, rval, pk = _plan_arrays_n(plan, meng, s0, s1, dtype, n)
     plan.close()
     osurf, oidx, oval = oracle.np_caf_surface(s0.astype(np.complex128), s1.astype(np.complex128), fr, FS)
-    assert np.max(np.abs(surf - osurf)) <= TOL32 * osurf.max() and (pk["freq"], int(pk["idx"])) == (12.0, lag)
+    assert np.max(np.abs(surf - osurf)) <= tol * osurf.max() and (pk["freq"], int(pk["idx"])) == (12.0, lag)
 
 
 def test_generic_path_still_covers_other_big_sizes(eng, oracle):

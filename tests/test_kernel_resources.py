@@ -44,8 +44,9 @@ def test_chain_kernels_register_shape():
     """The size-generic chain kernels (kernels_chain.hpp): LDS per workgroup within 160 KiB, the
     occupancy the launch code assumes (complex128: 2 waves per SIMD = 256 VGPRs, complex64: 4 = 128
     VGPRs), and spills bounded -- the R = 2 instantiations run (almost) spill-free since the butterfly
-    constants became SGPR operands; the 1024-thread R = 4 complex64 kernel (BASELINE configs[3]) sits at
-    60-90 spilled registers, a known cost, and must not get worse silently."""
+    constants became SGPR operands; the R = 4 complex64 kernel (BASELINE configs[3]) sits at
+    60-90 spilled registers and the R = 8 kernels (six live slab descriptors + the W_128 combine)
+    at 131 / 209, known costs that must not get worse silently."""
     usage = _usage()
     seen = 0
     for name, f in usage.items():
@@ -53,9 +54,9 @@ def test_chain_kernels_register_shape():
             continue
         seen += 1
         is_f64 = "k_chain_rowsId" in name
-        r4 = "ELi4ELi1ELi0E" in name
+        r = 8 if "ELi8ELi1ELi0E" in name else 4 if "ELi4ELi1ELi0E" in name else 2
         assert int(f["LDS Size [bytes/block]"]) <= 160 * 1024
         assert int(f["Occupancy [waves/SIMD]"]) == (2 if is_f64 else 4), name
-        limit = 100 if (r4 and not is_f64) else 30
+        limit = {2: 30, 4: 30 if is_f64 else 100, 8: 140 if is_f64 else 220}[r]
         assert int(f["VGPRs Spill"]) <= limit, (name, f["VGPRs Spill"])
-    assert seen == 9  # 4 complex128 + 5 complex64 instantiations
+    assert seen == 11  # 5 complex128 + 6 complex64 instantiations
