@@ -131,8 +131,10 @@ int caf_plan_create(caf_ctx *ctx, size_t n, const double *freqs_hz, size_t nfreq
                     uint32_t fs, int dtype, size_t row_begin, size_t row_end,
                     caf_plan **out);
 int caf_plan_destroy(caf_plan *plan);
-/* Name of the kernel path the plan selected: "fused4096" (n = 4096), "tiled65536"
- * (n = 32768) or "generic" (any other power of two). */
+/* Name of the kernel path the plan selected: "fused4096" (n = 4096), "chain" (every other n
+ * from 1024 to 65536 in complex64 / 32768 in complex128: LDS-resident single-pass rows) or
+ * "generic" (any other power of two: radix-2 passes over HBM).  The measurement build can
+ * also report "tiled65536" (round 1's three-pass n = 32768 form). */
 const char *caf_plan_path(const caf_plan *plan);
 size_t caf_plan_rows(const caf_plan *plan);
 /* Name of the dominant (row) kernel the plan launches, as rocprofv3 prints it without
@@ -184,8 +186,8 @@ int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, 
  * slots sustain the most single-surface replays per second on MI355X.  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
  * only (tau, f) + per-row peaks come back, as SURVEY.md section 8d prescribes.
  * Plans whose row kernel keeps its intermediate data on-chip ("fused4096", "chain") give
- * every slot private device state, so slots execute concurrently.  Plans on the "tiled65536"
- * and "generic" paths share the plan's pass workspaces: their slots run on ONE stream, in
+ * every slot private device state, so slots execute concurrently.  Plans on the
+ * "generic" path share the plan's pass workspaces: their slots run on ONE stream, in
  * submit order (slot k+1's H2D waits for slot k's kernels).
  * Lifetime: the captured graphs hold pointers into the plan's tables and workspaces;
  * caf_plan_destroy and caf_ctx_destroy return CAF_ERR_STATE while a caf_stream of the plan
