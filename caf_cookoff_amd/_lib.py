@@ -28,6 +28,7 @@ CAF_C64 = 1
 CAF_VIEW_GO = 1
 CAF_VIEW_PYTHON = 2
 CAF_STREAM_SPLIT = 1
+CAF_STREAM_THREE_KERNELS = 2
 
 
 class CafPeak(ctypes.Structure):
@@ -81,6 +82,7 @@ SYMBOLS = [
     ("caf_stream_create_ex", _int, [_vp, _sz, _int, _int, ctypes.c_uint, ctypes.POINTER(_vp)]),
     ("caf_stream_destroy", _int, [_vp]),
     ("caf_stream_host_buffers", _int, [_vp, _int, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    ("caf_stream_run", _int, [_vp, _vp, _vp, _sz, _pp, _up, _vp]),
     ("caf_stream_submit", _int, [_vp, _int]),
     ("caf_stream_wait", _int, [_vp, _int, _pp, _up, _vp]),
     ("caf_stream_surface", _vp, [_vp, _int]),

@@ -286,13 +286,18 @@ class Stream:
 
     PEAK_DTYPE = np.dtype([("val", "<f8"), ("freq", "<f8"), ("idx", "<u8"), ("row", "<i8")])
 
-    def __init__(self, plan: "Plan", batch: int, nslots: int = 2, want_surface: bool = True, split: bool = False):
+    def __init__(self, plan: "Plan", batch: int, nslots: int = 2, want_surface: bool = True, split: bool = False,
+                 three_kernels: bool = False):
         """``split``: the slot's graph holds ``batch`` independent single-surface node chains
-        (CAF_STREAM_SPLIT) instead of one batched chain."""
+        (CAF_STREAM_SPLIT) instead of one batched chain.  ``three_kernels``: single-surface chains of
+        n = 4096 plans as {spectrum, rows, find_peak} nodes instead of the one-launch surface kernel
+        (CAF_STREAM_THREE_KERNELS, for comparison)."""
         self.plan, self.batch, self.nslots = plan, int(batch), int(nslots)
         h = ctypes.c_void_p()
         plan.eng._check(plan.eng.lib.caf_stream_create_ex(plan._h, self.batch, self.nslots, int(bool(want_surface)),
-                                                          _lib.CAF_STREAM_SPLIT if split else 0, ctypes.byref(h)))
+                                                          (_lib.CAF_STREAM_SPLIT if split else 0)
+                                                          | (_lib.CAF_STREAM_THREE_KERNELS if three_kernels else 0),
+                                                          ctypes.byref(h)))
         self._h = h
         plan._streams.add(self)
         self._cdt = np.complex128 if plan.dtype == "c128" else np.complex64
@@ -319,6 +324,23 @@ class Stream:
         self.plan.eng._check(self.plan.eng.lib.caf_stream_wait(
             self._h, int(slot), peaks.ctypes.data_as(ctypes.POINTER(CafPeak)),
             _uptr(ridx) if want_rows else None, ctypes.c_void_p(rval.ctypes.data) if want_rows else None))
+        return peaks, ridx, rval
+
+    def run(self, needles, haystacks, want_rows: bool = False):
+        """``caf_stream_run``: all ``count`` host-resident pairs through the slots in one native loop.
+        needles / haystacks: [count][n] complex arrays of the plan's dtype (C-contiguous)."""
+        nd = np.ascontiguousarray(needles, dtype=self._cdt)
+        hs = np.ascontiguousarray(haystacks, dtype=self._cdt)
+        if nd.ndim != 2 or nd.shape != hs.shape or nd.shape[1] != self.plan.n:
+            raise ValueError("needles / haystacks must be [count][n]")
+        count = nd.shape[0]
+        peaks = np.zeros(count, dtype=self.PEAK_DTYPE)
+        ridx = np.zeros((count, self.plan.rows), dtype=np.uint64) if want_rows else None
+        rval = np.zeros((count, self.plan.rows), dtype=self._rdt) if want_rows else None
+        self.plan.eng._check(self.plan.eng.lib.caf_stream_run(
+            self._h, ctypes.c_void_p(nd.ctypes.data), ctypes.c_void_p(hs.ctypes.data), count,
+            peaks.ctypes.data_as(ctypes.POINTER(CafPeak)), _uptr(ridx) if want_rows else None,
+            ctypes.c_void_p(rval.ctypes.data) if want_rows else None))
         return peaks, ridx, rval
 
     def surface_ptr(self, slot: int) -> int:

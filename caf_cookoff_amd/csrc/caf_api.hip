@@ -2,6 +2,7 @@
 // No torch types, no CPU fallback: every entry point fails loudly without a GPU.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +17,7 @@
 #include "../../include/caf_hip.h"
 #include "kernels_fused4096.hpp"
 #include "kernels_seq4096.hpp"
+#include "kernels_surf4096.hpp"
 #include "kernels_duo4096.hpp"
 #include "kernels_chain.hpp"
 #include "kernels_generic.hpp"
@@ -385,7 +387,10 @@ extern "C" int caf_xcor_c64(caf_ctx *c, const float *a, const float *b, size_t n
 static bool chain_config(size_t n, int dtype, int *logm, int *R)
 {
     if (n < 1024 || n == (size_t)F_N || !is_pow2(n)) return false;
-    const size_t m_max = dtype == CAF_C64 ? 16384 : 8192;
+    size_t m_max = dtype == CAF_C64 ? 16384 : 8192;
+#ifdef CAF_MEASURE
+    if (dtype == CAF_C64 && measure_env("CAF_CHAIN_MMAX", 0)) m_max = (size_t)measure_env("CAF_CHAIN_MMAX", 0);  // 8192: shorter chains, more of them
+#endif
     size_t M;
     if (n <= m_max) { M = n; *R = 2; }
     else if (n / 2 <= m_max) { M = n / 2; *R = 4; }
@@ -406,12 +411,17 @@ static bool chain_config(size_t n, int dtype, int *logm, int *R)
         (void)NB_;                                                                               \
         STMT;                                                                                    \
     } else
+#ifdef CAF_MEASURE
+#define CHAIN_CASES_MEASURE_F32(STMT) CHAIN_CASE(13, 4, STMT) CHAIN_CASE(13, 8, STMT)
+#else
+#define CHAIN_CASES_MEASURE_F32(STMT)
+#endif
 #define CHAIN_DISPATCH(T, logm, R, STMT)                                                               \
     do {                                                                                               \
         const int logm_ = (logm), R_rt = (R);                                                          \
         if constexpr (sizeof(T) == 4) {                                                                \
             CHAIN_CASE(10, 2, STMT) CHAIN_CASE(11, 2, STMT) CHAIN_CASE(13, 2, STMT) CHAIN_CASE(14, 2, STMT) \
-            CHAIN_CASE(14, 4, STMT) CHAIN_CASE(14, 8, STMT)                                            \
+            CHAIN_CASE(14, 4, STMT) CHAIN_CASE(14, 8, STMT) CHAIN_CASES_MEASURE_F32(STMT)              \
             return fail(CAF_ERR_STATE, "chain path: no kernel for M=2^%d R=%d", logm_, R_rt);           \
         } else {                                                                                       \
             CHAIN_CASE(10, 2, STMT) CHAIN_CASE(11, 2, STMT) CHAIN_CASE(13, 2, STMT) CHAIN_CASE(13, 4, STMT) \
@@ -783,6 +793,49 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     return CAF_OK;
 }
 
+// One surface = ONE launch (kernels_surf4096.hpp): needle staging, haystack spectrum, Doppler rows and
+// find_peak as roles of one grid.  Used by single-surface streaming chains (caf_stream_*).
+template <typename T>
+static int surface_single_launch(caf_plan *p, hipStream_t on, const void *needle_src, void *d_needle, const void *hay,
+                                 void *spec, void *d_surface, uint64_t *d_ridx, void *d_rval, caf_peak *d_peak,
+                                 const PeakStageOut &host, unsigned *sync, unsigned *status, unsigned long long *h_seq)
+{
+    caf_ctx *c = p->ctx;
+    FusedArgs<T> a{};
+    a.phasor = (const cpx<T> *)p->d_phasor;
+    a.tab.tw4096 = (const cpx<T> *)c->tw4096[p->dtype];
+    a.tab.th = (const cpx<T> *)c->th[p->dtype];
+    a.spec = (cpx<T> *)spec;
+    a.sig = (const cpx<T> *)d_needle;
+    a.rows = (int)p->rows;
+    a.total = (int)p->rows;
+    a.surface = (T *)d_surface;
+    a.row_idx = d_ridx;
+    a.row_val = (T *)d_rval;
+    a.dbg = nullptr;
+    a.work = nullptr;
+    a.stage_src = (const uint4 *)needle_src;
+    a.stage_dst = (uint4 *)d_needle;
+    a.stage_n16 = needle_src ? (unsigned)(F_N * sizeof(cpx<T>) / 16) : 0u;
+    a.fft_blocks = 2;
+    SurfArgs<T> s{};
+    s.hay = (const cpx<T> *)hay;
+    s.sync = sync;
+    s.status = status;
+    s.copy_blocks = (a.stage_n16 + S_THREADS - 1) / S_THREADS;  // one 16-byte element per thread: all reads in flight at once
+    s.freqs = p->d_freqs;
+    s.row_base = (int64_t)p->row_begin;
+    s.peak = d_peak;
+    s.h_peak = host.peak;
+    s.h_ridx = host.row_idx;
+    s.h_rval = (T *)host.row_val;
+    s.h_seq = h_seq;
+    const unsigned grid = s.copy_blocks + 2u + (unsigned)p->rows;
+    k_seq_surface<T><<<grid, S_THREADS, 0, on>>>(a, a.phasor, s);
+    KCHK();
+    return CAF_OK;
+}
+
 #ifdef CAF_MEASURE
 // n = 32768 as 16 x 4096: two passes (kernels_q65536.hpp)
 template <typename T>
@@ -904,6 +957,11 @@ static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_ha
             case 16: k_chain_rows<T, 14, 4, 1, 16><<<grid, W, 0, c->stream>>>(a, phasor); break;
             case 30: k_chain_rows<T, 14, 4, 1, 30><<<grid, W, 0, c->stream>>>(a, phasor); break;
             case 31: k_chain_rows<T, 14, 4, 1, 31><<<grid, W, 0, c->stream>>>(a, phasor); break;
+            case 32: k_chain_rows<T, 14, 4, 1, 32><<<grid, W, 0, c->stream>>>(a, phasor); break;  // wave priorities by SIMD slot (correct results)
+            case 64: k_chain_rows<T, 14, 4, 1, 64><<<grid, W, 0, c->stream>>>(a, phasor); break;  // wave priorities by wave % 4 (correct results)
+            case 159: k_chain_rows<T, 14, 4, 1, 159><<<grid, W, 0, c->stream>>>(a, phasor); break;  // arithmetic only
+            case 128: k_chain_rows<T, 14, 4, 1, 128><<<grid, W, 0, c->stream>>>(a, phasor); break;  // no LDS chain traffic
+            case 62: k_chain_rows<T, 14, 4, 1, 62><<<grid, W, 0, c->stream>>>(a, phasor); break;  // priorities + no global memory
             case 200: k_chain_rows<T, 14, 4, 2, 0><<<grid, W / 2, 0, c->stream>>>(a, phasor); break;  // two butterflies per thread (correct results)
             default: return fail(CAF_ERR_BAD_ARG, "CAF_CHAIN_ABL=%d: no such ablation", abl);
             }
@@ -1217,6 +1275,10 @@ struct StreamSlot {
     void *d_ridx = nullptr, *d_rval = nullptr, *d_peak = nullptr;
     void *d_spec = nullptr;  // fused / chain plans: this slot's haystack spectra
     void *d_slab = nullptr;  // chain plans with R = 4: this slot's radix-4 scratch
+    unsigned *d_sync = nullptr;    // single-launch surfaces: 128 counter words (four 128-byte lines) per surface of the slot, zero between launches
+    unsigned *h_status = nullptr;  // pinned: set by a single-launch surface whose bounded wait ran out
+    unsigned long long *h_seq = nullptr;  // pinned [batch]: launches completed per single-launch surface (polled by caf_stream_wait)
+    unsigned long long submits = 0;       // replays of this slot's graph so far
     bool own_stream = true;
 };
 
@@ -1234,9 +1296,9 @@ static void stream_free(caf_stream *st)
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.exec) (void)hipGraphExecDestroy(s.exec);
         if (s.graph) (void)hipGraphDestroy(s.graph);
-        for (void *p : {s.h_needle, s.h_hay, s.h_peak, s.h_ridx, s.h_rval})
+        for (void *p : {s.h_needle, s.h_hay, s.h_peak, s.h_ridx, s.h_rval, (void *)s.h_status, (void *)s.h_seq})
             if (p) (void)hipHostFree(p);
-        for (void *p : {s.d_needle, s.d_surface, s.d_ridx, s.d_rval, s.d_peak, s.d_spec, s.d_slab})
+        for (void *p : {s.d_needle, s.d_surface, s.d_ridx, s.d_rval, s.d_peak, s.d_spec, s.d_slab, (void *)s.d_sync})
             if (p) (void)hipFree(p);
         if (s.stream && s.own_stream && st->plan) {  // back to the context's pool
             caf_ctx *c = st->plan->ctx;
@@ -1254,7 +1316,8 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     if (!p || !out) return fail(CAF_ERR_BAD_ARG, "caf_stream_create: NULL argument");
     *out = nullptr;
     if (batch == 0 || nslots < 2 || nslots > 16) return fail(CAF_ERR_BAD_ARG, "caf_stream_create: batch >= 1, 2 <= nslots <= 16");
-    if (flags & ~(unsigned)CAF_STREAM_SPLIT) return fail(CAF_ERR_BAD_ARG, "caf_stream_create_ex: unknown flags 0x%x", flags);
+    if (flags & ~(unsigned)(CAF_STREAM_SPLIT | CAF_STREAM_THREE_KERNELS))
+        return fail(CAF_ERR_BAD_ARG, "caf_stream_create_ex: unknown flags 0x%x", flags);
     const bool split = (flags & CAF_STREAM_SPLIT) && batch > 1;
     if (split && batch > 16) return fail(CAF_ERR_BAD_ARG, "caf_stream_create_ex: CAF_STREAM_SPLIT supports at most 16 surfaces per slot");
     caf_ctx *c = p->ctx;
@@ -1265,6 +1328,11 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     st->batch = batch;
     st->slots.resize(nslots);
     const bool private_state = p->fused || p->chain;  // slots (and split branches) own their spectra / scratch
+    // single-surface chains of the tuned n = 4096 path are ONE kernel node (kernels_surf4096.hpp)
+    bool one_launch = p->fused && p->rows > 0 && !(flags & CAF_STREAM_THREE_KERNELS) && (batch == 1 || split);
+#ifdef CAF_MEASURE
+    if (p->variant == 1 || p->variant == 2 || p->dbg) one_launch = false;  // measurement variants keep their own kernels
+#endif
     const size_t esz = elem_size(p->dtype), rsz = real_size(p->dtype);
     const size_t in1 = p->n * esz, in_bytes = batch * in1;
     const size_t rows = p->rows ? p->rows : 1;
@@ -1335,6 +1403,14 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
         SCHK(hipMalloc(&s.d_rval, rval_bytes));
         SCHK(hipMalloc(&s.d_peak, batch * sizeof(caf_peak)));
         if (want_surface) SCHK(hipMalloc(&s.d_surface, surf_bytes));
+        if (one_launch) {
+            SCHK(hipMalloc((void **)&s.d_sync, batch * 512));
+            SCHK(hipMemset(s.d_sync, 0, batch * 512));
+            SCHK(hipHostMalloc((void **)&s.h_status, 64, hipHostMallocDefault));
+            memset(s.h_status, 0, 64);
+            SCHK(hipHostMalloc((void **)&s.h_seq, batch * sizeof(unsigned long long), hipHostMallocDefault));
+            memset(s.h_seq, 0, batch * sizeof(unsigned long long));
+        }
         memset(s.h_needle, 0, in_bytes);
         memset(s.h_hay, 0, in_bytes);
     }
@@ -1374,6 +1450,22 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
         p->slab_override = slab;
         p->stage_out = PeakStageOut{(caf_peak *)(m_peak + first * sizeof(caf_peak)), (uint64_t *)(m_ridx + first * ridx1),
                                     (void *)(m_rval + first * rval1)};
+        if (one_launch && nsurf == 1) {
+            unsigned *m_status = nullptr;
+            unsigned long long *m_seq = nullptr;
+            HIPCHK(hipHostGetDevicePointer((void **)&m_status, s.h_status, 0));
+            HIPCHK(hipHostGetDevicePointer((void **)&m_seq, s.h_seq, 0));
+            const PeakStageOut ho = p->stage_out;
+            p->spec_override = nullptr;
+            p->slab_override = nullptr;
+            p->stage_out = PeakStageOut{nullptr, nullptr, nullptr};
+            unsigned *sy = s.d_sync + first * 128;
+            return p->dtype == CAF_C128
+                       ? surface_single_launch<double>(p, on, jin.src[0], dn, m_hay + first * in1, spec, ds, (uint64_t *)di, dv,
+                                                       (caf_peak *)dp, ho, sy, m_status, m_seq + first)
+                       : surface_single_launch<float>(p, on, jin.src[0], dn, m_hay + first * in1, spec, ds, (uint64_t *)di, dv,
+                                                      (caf_peak *)dp, ho, sy, m_status, m_seq + first);
+        }
         hipError_t e1 = hipSuccess;
         if (p->fused && p->variant != 2 && inb % 16 == 0) {  // the spectrum kernel stages the needles in itself
             p->stage_in_src = jin.src[0];
@@ -1400,6 +1492,10 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
         rc = chain(s, s.stream, 0, split ? 1 : batch, s.d_spec, s.d_slab);
         if (rc) return bail(rc);
         SCHK(hipStreamSynchronize(s.stream));
+        if (s.h_seq) {  // the warm-up was launch 1 of surface 0 only: start every surface of every slot from zero again
+            SCHK(hipMemset(s.d_sync, 0, batch * 512));
+            memset(s.h_seq, 0, batch * sizeof(unsigned long long));
+        }
     }
     p->timing = false;  // event records are not wanted inside the graphs
     for (auto &s : st->slots) {
@@ -1474,7 +1570,28 @@ extern "C" int caf_stream_submit(caf_stream *st, int slot)
     int rc = slot_ok(st, slot);
     if (rc) return rc;
     HIPCHK(hipSetDevice(st->plan->ctx->device));
+    ++st->slots[slot].submits;
     HIPCHK(hipGraphLaunch(st->slots[slot].exec, st->slots[slot].stream));
+    return CAF_OK;
+}
+
+// Completion of a slot whose surfaces are single launches: each writes its launch count to pinned memory
+// behind its results, so the host polls that word (~1 us after the last row) instead of waiting for the
+// stream's completion signal; the stream itself is only synchronised when the poll runs out of patience.
+static int slot_wait(StreamSlot &s, size_t batch)
+{
+    if (s.h_seq) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned long spins = 0;; ++spins) {
+            bool done = true;
+            for (size_t j = 0; j < batch; ++j)
+                done = done && __atomic_load_n(&s.h_seq[j], __ATOMIC_ACQUIRE) >= s.submits;
+            if (done) return CAF_OK;
+            __builtin_ia32_pause();
+            if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s.stream));
     return CAF_OK;
 }
 
@@ -1484,11 +1601,57 @@ extern "C" int caf_stream_wait(caf_stream *st, int slot, caf_peak *peaks, uint64
     if (rc) return rc;
     StreamSlot &s = st->slots[slot];
     HIPCHK(hipSetDevice(st->plan->ctx->device));
-    HIPCHK(hipStreamSynchronize(s.stream));
+    if ((rc = slot_wait(s, st->batch))) return rc;
+    if (s.h_status && *(volatile unsigned *)s.h_status) {  // a single-launch surface gave up waiting for its own lower tickets
+        *(volatile unsigned *)s.h_status = 0u;
+        HIPCHK(hipStreamSynchronize(s.stream));
+        HIPCHK(hipMemset(s.d_sync, 0, st->batch * 512));
+        memset(s.h_seq, 0, st->batch * sizeof(unsigned long long));
+        s.submits = 0;
+        return fail(CAF_ERR_HIP, "caf_stream_wait: slot %d: a surface launch ran into its wait bound; results discarded", slot);
+    }
     const size_t rows = st->plan->rows;
     if (peaks) memcpy(peaks, s.h_peak, st->batch * sizeof(caf_peak));
     if (row_idx && rows) memcpy(row_idx, s.h_ridx, st->batch * rows * sizeof(uint64_t));
     if (row_val && rows) memcpy(row_val, s.h_rval, st->batch * rows * real_size(st->plan->dtype));
+    return CAF_OK;
+}
+
+// The whole streaming loop in native code (BASELINE configs[4]: `count` host-resident pairs, one after the
+// other): fill slot k's pinned buffers, replay its graph, collect slot k - nslots + 1 ... so that the
+// caller pays one call for the run instead of three per step.
+extern "C" int caf_stream_run(caf_stream *st, const void *needles, const void *haystacks, size_t count, caf_peak *peaks,
+                              uint64_t *row_idx, void *row_val)
+{
+    if (!st) return fail(CAF_ERR_BAD_ARG, "stream is NULL");
+    if (count && (!needles || !haystacks || !peaks)) return fail(CAF_ERR_BAD_ARG, "caf_stream_run: NULL argument");
+    const caf_plan *p = st->plan;
+    const size_t batch = st->batch, nslots = st->slots.size(), rows = p->rows;
+    const size_t in1 = p->n * elem_size(p->dtype), rsz = real_size(p->dtype);
+    const size_t nsteps = (count + batch - 1) / batch;
+    HIPCHK(hipSetDevice(p->ctx->device));
+    for (size_t step = 0; step < nsteps + nslots; ++step) {
+        StreamSlot &s = st->slots[step % nslots];
+        if (step >= nslots && step - nslots < nsteps) {  // collect what this slot carried nslots steps ago
+            const size_t first = (step - nslots) * batch, k = count - first < batch ? count - first : batch;
+            int rc = caf_stream_wait(st, (int)(step % nslots), nullptr, nullptr, nullptr);
+            if (rc) return rc;
+            memcpy(peaks + first, s.h_peak, k * sizeof(caf_peak));
+            if (row_idx && rows) memcpy(row_idx + first * rows, s.h_ridx, k * rows * sizeof(uint64_t));
+            if (row_val && rows) memcpy((char *)row_val + first * rows * rsz, s.h_rval, k * rows * rsz);
+        }
+        if (step < nsteps) {
+            const size_t first = step * batch, k = count - first < batch ? count - first : batch;
+            memcpy(s.h_needle, (const char *)needles + first * in1, k * in1);
+            memcpy(s.h_hay, (const char *)haystacks + first * in1, k * in1);
+            if (k < batch) {  // ragged tail: the unused surfaces of the slot run on zeros, their results are dropped
+                memset((char *)s.h_needle + k * in1, 0, (batch - k) * in1);
+                memset((char *)s.h_hay + k * in1, 0, (batch - k) * in1);
+            }
+            ++s.submits;
+            HIPCHK(hipGraphLaunch(s.exec, s.stream));
+        }
+    }
     return CAF_OK;
 }
 

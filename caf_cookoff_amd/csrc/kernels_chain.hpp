@@ -202,7 +202,8 @@ __device__ __forceinline__ void small_stage(cpx<T> (&v)[16])
 // 1.02 vs 0.91 ms without global memory: two waves per SIMD with 116 spilled registers, and a
 // 4-bit lgkmcnt cannot wait for "all but the other slot's 32 operations".
 // ABL (measurement build only, WRONG results, timing only): bit 0 = no workgroup barriers, bit 1 = no
-// haystack-spectrum loads, bit 2 = no slab traffic, bit 3 = no needle loads, bit 4 = no surface stores.
+// haystack-spectrum loads, bit 2 = no slab traffic, bit 3 = no needle loads, bit 4 = no surface stores, bit 7 = no LDS chain traffic;
+// bits 5 / 6 (correct results): static wave priorities, see k_chain_rows.
 template <typename T, int LOGM, int NB = 1, int ABL = 0>
 struct ChainLane {
     using G = ChainGeo<LOGM>;
@@ -263,6 +264,17 @@ struct ChainLane {
         }
     }
 
+    // chain element accessors (ABL bit 7, measurement: no LDS data traffic)
+    __device__ __forceinline__ void st(int pos, C x) const
+    {
+        if constexpr (ABL & 128) keep(x);
+        else Lc[pos] = x;
+    }
+    __device__ __forceinline__ C ld(int pos) const
+    {
+        if constexpr (ABL & 128) { C x = C{T(pos), T(1)}; keep(x); return x; }
+        else return Lc[pos];
+    }
     // synchronise the exchange that follows radix-16 stage s
     template <int S>
     __device__ __forceinline__ void sync_after() const
@@ -279,10 +291,10 @@ struct ChainLane {
     {
         if constexpr (strided<S>()) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = Lc[base[b][S < 3 ? S : 0] + G::off(S, j)];
+            for (int j = 0; j < 16; ++j) v[j] = ld(base[b][S < 3 ? S : 0] + G::off(S, j));
         } else {  // S = 1 radix-16 stage or the small last stage: 16 contiguous elements
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = Lc[basef[b] + j];
+            for (int j = 0; j < 16; ++j) v[j] = ld(basef[b] + j);
         }
     }
     template <int S>
@@ -290,10 +302,10 @@ struct ChainLane {
     {
         if constexpr (strided<S>()) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) Lc[base[b][S < 3 ? S : 0] + G::off(S, j)] = v[j];
+            for (int j = 0; j < 16; ++j) st(base[b][S < 3 ? S : 0] + G::off(S, j), v[j]);
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) Lc[basef[b] + j] = v[j];
+            for (int j = 0; j < 16; ++j) st(basef[b] + j, v[j]);
         }
     }
     // twiddle W_{B_S}^(o k) of radix-16 stage S >= 1 from its LDS table
@@ -319,7 +331,7 @@ struct ChainLane {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const TwFold<T> f0(tw[b], lane[b]);
-            dft16_sink(v[b], [&](int k, C x) { Lc[base[b][0] + G::off(0, k)] = twA_k(x, k, tw[b], f0); });
+            dft16_sink(v[b], [&](int k, C x) { st(base[b][0] + G::off(0, k), twA_k(x, k, tw[b], f0)); });
         }
         sync_after<0>();
 #pragma unroll
@@ -336,7 +348,7 @@ struct ChainLane {
         } else {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                dft16_sink(v[b], [&](int k, C x) { Lc[base[b][S < 3 ? S : 0] + G::off(S, k)] = k ? cmul(x, twk<S>(k, b)) : x; });
+                dft16_sink(v[b], [&](int k, C x) { st(base[b][S < 3 ? S : 0] + G::off(S, k), k ? cmul(x, twk<S>(k, b)) : x); });
                 sync_after<S>();  // wave-local (static_assert above)
                 rd<S + 1>(v[b], b);
                 if constexpr (NB > 1) __builtin_amdgcn_sched_barrier(0);
@@ -374,7 +386,7 @@ struct ChainLane {
 #pragma unroll
                 for (int k = 1; k < 16; ++k) v[b][k] = cmul(v[b][k], twk<S>(k, b));
                 wave_lds_fence();
-                dft16_sink(v[b], [&](int k, C x) { Lc[base[b][S < 3 ? S : 0] + G::off(S, k)] = x; });
+                dft16_sink(v[b], [&](int k, C x) { st(base[b][S < 3 ? S : 0] + G::off(S, k), x); });
             }
             if constexpr (local) {
                 wave_lds_fence();
@@ -609,6 +621,14 @@ __global__ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cp
     T *const sv = reinterpret_cast<T *>(scratch);
     uint32_t *const si = reinterpret_cast<uint32_t *>(scratch + 128);
     const int lane = L.t & 63, wave = L.t >> 6;
+    if constexpr ((ABL & 96) != 0) {
+        // measurement: static issue priorities for the waves that share a SIMD (wave w sits on SIMD w % 4), so
+        // that they run staggered between workgroup barriers instead of in the same phase
+        const int slot = (ABL & 64) ? (__builtin_amdgcn_readfirstlane(wave) & 3) : ((__builtin_amdgcn_readfirstlane(wave) >> 2) & 3);
+        if (slot == 0) __builtin_amdgcn_s_setprio(3);
+        else if (slot == 1) __builtin_amdgcn_s_setprio(2);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(1);
+    }
     __syncthreads();
 
     for (int g = blockIdx.x; g < A.total; g += gridDim.x) {

@@ -81,11 +81,16 @@ constexpr int S_NSTAMP = 28;
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
 
-template <typename T, int CH, int ABL = 0, int PF = 0>
+// HW: called once before the haystack-spectrum values are requested (k_seq_surface waits there for the
+// workgroups that compute them; a no-op everywhere else)
+struct SeqNoWait {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <typename T, int CH, int ABL = 0, int PF = 0, typename HW = SeqNoWait>
 __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t rs_sig,
                                           const __amdgpu_buffer_rsrc_t rs_spec, const cpx<T> pb, const cpx<T> post,
                                           const cpx<T> *__restrict__ ps, const TwSet<T> &tw, const cpx<T> *twB,
-                                          cpx<T> *Lc, const SeqLane &L, unsigned long long (&st)[S_NSTAMP])
+                                          cpx<T> *Lc, const SeqLane &L, unsigned long long (&st)[S_NSTAMP], HW hwait = HW{})
 {
     SEQ_STAMP(0);
     using C = cpx<T>;
@@ -108,6 +113,7 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
     }
     const TwFold<T> fmix(tw, conj(pb));
     if constexpr (H_EARLY) {
+        hwait();
 #pragma unroll
         for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
     }
@@ -134,11 +140,13 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
         for (int k = 0; k < 16; ++k) v[k] = Lc[L.pC + k];
     }
     if constexpr (H_MID) {
+        hwait();
 #pragma unroll
         for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
     }
     dft16(v);
     SEQ_STAMP(5);  // ex2 read + DFT#3
+    if constexpr (!(H_EARLY || H_MID)) hwait();
     // ---- spectrum product (xcor_rustfft.rs:64-73) ------------------------------------------
 #pragma unroll
     for (int k = 0; k < 16; ++k) {

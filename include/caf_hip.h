@@ -200,13 +200,25 @@ int caf_stream_create(caf_plan *plan, size_t batch, int nslots, int want_surface
  * stage-out) instead of one batched chain -- as parallel branches when the plan's per-slot state
  * is private ("fused4096", "chain"), in series otherwise.  One replay then retires `batch`
  * surfaces at single-surface granularity; host buffers and results are laid out as in the
- * batched mode. */
-enum caf_stream_flags { CAF_STREAM_SPLIT = 1 };
+ * batched mode.
+ * Single-surface chains (batch == 1, or CAF_STREAM_SPLIT) of "fused4096" plans are ONE kernel
+ * node: needle staging, haystack spectrum, Doppler rows and find_peak run as roles of one launch
+ * (csrc/kernels_surf4096.hpp).  CAF_STREAM_THREE_KERNELS keeps the three-node form {spectrum,
+ * rows, find_peak} for comparison. */
+enum caf_stream_flags { CAF_STREAM_SPLIT = 1, CAF_STREAM_THREE_KERNELS = 2 };
 int caf_stream_create_ex(caf_plan *plan, size_t batch, int nslots, int want_surface, unsigned flags,
                          caf_stream **out);
 int caf_stream_destroy(caf_stream *st);
 /* Pinned host buffers of a slot: [batch][n] complex each (dtype of the plan). */
 int caf_stream_host_buffers(caf_stream *st, int slot, void **needle, void **haystack);
+/* The whole loop in one call: `count` host-resident pairs (needles / haystacks: [count][n] complex of
+ * the plan's dtype, ordinary host memory) go through the slots in order, `batch` per replay (a ragged
+ * last replay is padded with zeros); peaks[count] and, if non-NULL, row_idx / row_val [count][rows]
+ * come back in input order.  Surfaces stay in the slots (caf_stream_surface).  This is BASELINE
+ * configs[4] as a compiled host would run it: one native loop over the pairs (the reference's
+ * benches call caf_surface once per iteration from Rust, caf_bench.rs:150-168). */
+int caf_stream_run(caf_stream *st, const void *needles, const void *haystacks, size_t count, caf_peak *peaks,
+                   uint64_t *row_idx, void *row_val);
 /* Replay the slot's graph on the slot's stream (asynchronous). */
 int caf_stream_submit(caf_stream *st, int slot);
 /* Block until the slot's last submit finished; copies out `batch` caf_peak records and,

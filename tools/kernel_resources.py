@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Print hipcc's kernel-resource-usage remarks (make -C caf_cookoff_amd/csrc asm) per kernel:
-VGPRs, spills, scratch, occupancy, LDS.  usage: kernel_resources.py [substring]"""
+VGPRs, spills, scratch, occupancy, LDS.  usage: kernel_resources.py [substring] [measure]
+("measure": the measurement build, after make -C caf_cookoff_amd/csrc asm-measure)"""
 import re
 import subprocess
 import sys
 from pathlib import Path
 
-txt = (Path(__file__).resolve().parent.parent / "caf_cookoff_amd/csrc/build/resource_usage.txt").read_text()
+which = "resource_usage_measure.txt" if "measure" in sys.argv[2:] else "resource_usage.txt"
+txt = (Path(__file__).resolve().parent.parent / "caf_cookoff_amd/csrc/build" / which).read_text()
 want = sys.argv[1] if len(sys.argv) > 1 else ""
 for m in re.finditer(r"Function Name: (\S+)(.*?)(?=Function Name:|\Z)", txt, re.S):
     f = dict(re.findall(r"remark:\s+([A-Za-z \[\]/]+?): (\S+) \[-Rpass", m.group(2)))
