@@ -120,6 +120,50 @@ class Xcor {  // xcor_rustfft.rs:14-93
     std::size_t n_;
 };
 
+// Back-to-back surfaces from host memory (BASELINE configs[4]; the reference has no counterpart: its
+// benches call caf_surface once per iteration, caf_bench.rs:150-168).  One plan + one caf_stream, RAII;
+// run() is one native loop over all pairs (caf_stream_run) and returns find_peak's answer per pair.
+class CafHipStream {
+  public:
+    CafHipStream(std::size_t n, const std::vector<double> &freqs_hz, uint32_t fs, int nslots = 2) : n_(n)
+    {
+        check(caf_plan_create(default_ctx(), n, freqs_hz.data(), freqs_hz.size(), fs, CAF_C128, 0, freqs_hz.size(), &plan_),
+              "caf_plan_create");
+        if (int rc = caf_stream_create(plan_, 1, nslots, 0, &stream_)) {
+            caf_plan_destroy(plan_);
+            check(rc, "caf_stream_create");
+        }
+    }
+    CafHipStream(const CafHipStream &) = delete;
+    CafHipStream &operator=(const CafHipStream &) = delete;
+    ~CafHipStream()
+    {
+        caf_stream_destroy(stream_);
+        caf_plan_destroy(plan_);
+    }
+    std::vector<std::pair<double, std::size_t>> run(const std::vector<std::vector<Complex64>> &needles,
+                                                    const std::vector<std::vector<Complex64>> &haystacks)
+    {
+        if (needles.size() != haystacks.size()) throw std::runtime_error("CafHipStream::run: needles vs haystacks");
+        std::vector<Complex64> a(needles.size() * n_), b(needles.size() * n_);
+        for (std::size_t k = 0; k < needles.size(); ++k) {
+            if (needles[k].size() != n_ || haystacks[k].size() != n_) throw std::runtime_error("CafHipStream::run: length");
+            std::copy(needles[k].begin(), needles[k].end(), a.begin() + k * n_);
+            std::copy(haystacks[k].begin(), haystacks[k].end(), b.begin() + k * n_);
+        }
+        std::vector<caf_peak> pk(needles.size());
+        check(caf_stream_run(stream_, a.data(), b.data(), needles.size(), pk.data(), nullptr, nullptr), "caf_stream_run");
+        std::vector<std::pair<double, std::size_t>> out;
+        for (const caf_peak &p : pk) out.emplace_back(p.freq, static_cast<std::size_t>(p.idx));
+        return out;
+    }
+
+  private:
+    std::size_t n_;
+    caf_plan *plan_ = nullptr;
+    caf_stream *stream_ = nullptr;
+};
+
 // utils.rs:10-35: packed LE f32 I/Q pairs -> Complex64
 inline std::vector<Complex64> read_file_c64(const std::string &filename)
 {

@@ -70,6 +70,33 @@ int main(int argc, char **argv)
         ASSERT_EQ(threw, true);
         std::printf("test xcor_length_assert ... %s\n", threw ? "ok" : "FAILED");
     }
+    // streaming (BASELINE configs[4]): the ten pairs back to back through one caf_stream on chirp 9's shift
+    // list give, pair by pair, what caf_surface + find_peak give on that list; pair 9 is the reference's KAT
+    {
+        const char *hay[10] = {"chirp_0_T+202samp_F+69.25Hz.c64", "chirp_1_T+78samp_F+35.99Hz.c64",
+                               "chirp_2_T+169samp_F+32.16Hz.c64", "chirp_3_T+151samp_F-76.22Hz.c64",
+                               "chirp_4_T+70samp_F+82.89Hz.c64", "chirp_5_T+177samp_F-92.72Hz.c64",
+                               "chirp_6_T+15samp_F-49.69Hz.c64", "chirp_7_T+84samp_F+68.26Hz.c64",
+                               "chirp_8_T+80samp_F-46.28Hz.c64", "chirp_9_T+176samp_F+61.49Hz.c64"};
+        auto shifts = gen_float_shifts(-100.0, 100.0, 0.5);
+        std::vector<std::vector<Complex64>> nd, hs;
+        for (int k = 0; k < 10; ++k) {
+            auto files = load_files(data_dir + "chirp_" + std::to_string(k) + "_raw.c64", data_dir + hay[k]);
+            nd.push_back(files.first);
+            hs.push_back(files.second);
+        }
+        CafHipStream stream(nd[0].size(), shifts, 48000);
+        auto got = stream.run(nd, hs);
+        const int before = failures;
+        for (int k = 0; k < 10; ++k) {
+            auto want = CafHip::find_peak(CafHip::caf_surface(nd[k], hs[k], shifts, 48000));
+            ASSERT_EQ(got[k].first, want.first);
+            ASSERT_EQ(got[k].second, want.second);
+        }
+        ASSERT_EQ(got[9].first, 61.5);
+        ASSERT_EQ(got[9].second, 176);
+        std::printf("test hip_stream_ten_pairs ... %s\n", failures == before ? "ok" : "FAILED");
+    }
     std::printf("test result: %s. %d failed\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;
 }
