@@ -196,9 +196,15 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_surf
     // PF 8: samples preloaded; no early spectrum request in the even chain (the wait sits in front of the
     // product instead, behind the whole forward transform); 2 | 4: the odd chain's loads as in k_seq_rows
     constexpr int PF = 2 | 4 | 8;
+    // the spectrum counter is requested here and looked at behind the forward transform: in the usual case
+    // (spectrum ready by then) the wait costs nothing, not even the round trip of one poll; otherwise every
+    // wave polls for itself (no barrier inside the chain)
     bool okh = true;
+    const unsigned h_early = __hip_atomic_load(&S.sync[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     seq_chain<T, 0, 0, PF>(e, a, rs_sig, rs_spec, pb, th, ph + 32, tw, twB, Lc, L, st, [&]() {
-        okh = surf_wait_wg(&S.sync[64], 2u, sh + 3, L.wave);
+        if (__builtin_amdgcn_readfirstlane(h_early) < 2u) okh = surf_wait(&S.sync[64], 2u);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     });
     seq_chain<T, 1, 0, PF>(o, a, rs_sig, rs_spec, cmul(pb, cfac), th, ph + 48, tw, twB, Lc, L, st);
 
