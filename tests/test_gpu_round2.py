@@ -459,6 +459,44 @@ def test_stream_single_launch_surface(dtype, nrows, eng, oracle):
         assert np.max(np.abs(one[1] - ref[1])) <= 1e-13 * osurf.max()
 
 
+@pytest.mark.parametrize("dtype", ["c128", "c64"])
+def test_stream_single_launch_edge_inputs(dtype, eng):
+    """The one-launch surface kernel on the inputs the reference's comparison rule is sensitive to (mod.rs:
+    32-35, 143-151): all-zero pair -> every row (0, 0.0), peak (0.0, 0) with row -1; NaN in the needle / in
+    the haystack -> the same; an exact two-row tie -> the first row wins; then an ordinary pair on the same
+    slots (the counters re-arm after every one of these).  Each answer equals the batched API's."""
+    import caf_cookoff_amd as caf
+    rng = np.random.default_rng(11)
+    n = 4096
+    cdt = np.complex128 if dtype == "c128" else np.complex64
+    a = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cdt)
+    b = np.roll(a, 21)
+    z = np.zeros(n, dtype=cdt)
+    an, bn = a.copy(), b.copy()
+    an[n // 3] = complex(np.nan, 1.0)
+    bn[7] = complex(1.0, np.nan)
+    fr = np.array([-2.5, 0.0, 0.0, 4.0])  # rows 1 and 2 tie exactly
+    cases = [(z, z), (an, b), (a, bn), (a, b), (b, a)]
+    plan = eng.plan(n, fr, FS, dtype=dtype)
+    st = caf.Stream(plan, batch=1, nslots=2, want_surface=False)
+    try:
+        nd = np.stack([c[0] for c in cases])
+        hs = np.stack([c[1] for c in cases])
+        peaks, ridx, rval = st.run(nd, hs, want_rows=True)
+    finally:
+        st.close()
+        plan.close()
+    for k, (x, y) in enumerate(cases):
+        _, ri, rv, pk = eng.surface_arrays(x, y, fr, FS, dtype=dtype, want_surface=False)
+        assert (float(peaks[k]["freq"]), int(peaks[k]["idx"]), int(peaks[k]["row"])) == (pk.freq, pk.idx, pk.row), k
+        assert np.array_equal(ridx[k], ri), k
+        assert np.allclose(rval[k], rv, rtol=1e-12 if dtype == "c128" else 1e-4, atol=0.0), k
+    for k in (0, 1, 2):
+        assert (float(peaks[k]["freq"]), int(peaks[k]["idx"]), float(peaks[k]["val"]), int(peaks[k]["row"])) == (0.0, 0, 0.0, -1)
+        assert not ridx[k].any() and not rval[k].any()
+    assert int(peaks[3]["row"]) == 1 and int(peaks[3]["idx"]) == 21 and float(peaks[3]["freq"]) == 0.0
+
+
 @pytest.mark.parametrize("dtype,batch,nslots,split", [("c128", 1, 2, False), ("c128", 1, 3, False), ("c128", 4, 2, True),
                                                       ("c128", 4, 2, False), ("c64", 1, 2, False), ("c64", 3, 2, True)])
 def test_stream_run_native_loop(dtype, batch, nslots, split, eng, oracle):
