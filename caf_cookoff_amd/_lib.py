@@ -29,6 +29,8 @@ CAF_VIEW_GO = 1
 CAF_VIEW_PYTHON = 2
 CAF_STREAM_SPLIT = 1
 CAF_STREAM_THREE_KERNELS = 2
+CAF_STREAM_TWO_KERNELS = 4
+CAF_STREAM_ONE_KERNEL = 8
 
 
 class CafPeak(ctypes.Structure):

@@ -798,7 +798,8 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
 template <typename T>
 static int surface_single_launch(caf_plan *p, hipStream_t on, const void *needle_src, void *d_needle, const void *hay,
                                  void *spec, void *d_surface, uint64_t *d_ridx, void *d_rval, caf_peak *d_peak,
-                                 const PeakStageOut &host, unsigned *sync, unsigned *status, unsigned long long *h_seq)
+                                 const PeakStageOut &host, unsigned *sync, unsigned *status, unsigned long long *h_seq,
+                                 bool two_nodes)
 {
     caf_ctx *c = p->ctx;
     FusedArgs<T> a{};
@@ -822,7 +823,21 @@ static int surface_single_launch(caf_plan *p, hipStream_t on, const void *needle
     s.hay = (const cpx<T> *)hay;
     s.sync = sync;
     s.status = status;
+    if (two_nodes) {
+        // node 1: needle staging + haystack spectrum (k_seq_prepare, 16 + 2 workgroups); node 2 below then never waits
+        FusedArgs<T> pa = a;
+        pa.sig = (const cpx<T> *)hay;
+        pa.total = 1;
+        pa.rows = (int)p->rows;
+        pa.work = nullptr;
+        pa.surface = nullptr; pa.row_idx = nullptr; pa.row_val = nullptr;
+        const unsigned cb = (a.stage_n16 + S_THREADS - 1) / S_THREADS;
+        k_seq_prepare<T><<<2u + cb, S_THREADS, 0, on>>>(pa, pa.phasor);
+        KCHK();
+        a.stage_src = nullptr; a.stage_dst = nullptr; a.stage_n16 = 0;
+    }
     s.copy_blocks = (a.stage_n16 + S_THREADS - 1) / S_THREADS;  // one 16-byte element per thread: all reads in flight at once
+    s.prep_blocks = two_nodes ? 0u : 2u;
     s.freqs = p->d_freqs;
     s.row_base = (int64_t)p->row_begin;
     s.peak = d_peak;
@@ -830,7 +845,7 @@ static int surface_single_launch(caf_plan *p, hipStream_t on, const void *needle
     s.h_ridx = host.row_idx;
     s.h_rval = (T *)host.row_val;
     s.h_seq = h_seq;
-    const unsigned grid = s.copy_blocks + 2u + (unsigned)p->rows;
+    const unsigned grid = s.copy_blocks + s.prep_blocks + (unsigned)p->rows;
     k_seq_surface<T><<<grid, S_THREADS, 0, on>>>(a, a.phasor, s);
     KCHK();
     return CAF_OK;
@@ -1316,7 +1331,7 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     if (!p || !out) return fail(CAF_ERR_BAD_ARG, "caf_stream_create: NULL argument");
     *out = nullptr;
     if (batch == 0 || nslots < 2 || nslots > 16) return fail(CAF_ERR_BAD_ARG, "caf_stream_create: batch >= 1, 2 <= nslots <= 16");
-    if (flags & ~(unsigned)(CAF_STREAM_SPLIT | CAF_STREAM_THREE_KERNELS))
+    if (flags & ~(unsigned)(CAF_STREAM_SPLIT | CAF_STREAM_THREE_KERNELS | CAF_STREAM_TWO_KERNELS | CAF_STREAM_ONE_KERNEL))
         return fail(CAF_ERR_BAD_ARG, "caf_stream_create_ex: unknown flags 0x%x", flags);
     const bool split = (flags & CAF_STREAM_SPLIT) && batch > 1;
     if (split && batch > 16) return fail(CAF_ERR_BAD_ARG, "caf_stream_create_ex: CAF_STREAM_SPLIT supports at most 16 surfaces per slot");
@@ -1330,6 +1345,12 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     const bool private_state = p->fused || p->chain;  // slots (and split branches) own their spectra / scratch
     // single-surface chains of the tuned n = 4096 path are ONE kernel node (kernels_surf4096.hpp)
     bool one_launch = p->fused && p->rows > 0 && !(flags & CAF_STREAM_THREE_KERNELS) && (batch == 1 || split);
+    // One node {staging, spectrum, rows, find_peak} or two {staging + spectrum | rows + find_peak}?  In the one-node
+    // form the row workgroups of a launch hold their CU slots while the needle crosses PCIe (~5 us of 33); with
+    // two surfaces in flight that costs less than a second node's launch gap, from three on it is the other way
+    // round (MI355X: 2 slots 45.5 k vs 38.5 k surfaces/s, 3 slots 50 k vs 55 k, 4 slots 52 k vs 58 k).
+    const size_t in_flight = (size_t)nslots * (split ? batch : 1);
+    const bool two_nodes = (flags & CAF_STREAM_TWO_KERNELS) || (!(flags & CAF_STREAM_ONE_KERNEL) && in_flight > 2);
 #ifdef CAF_MEASURE
     if (p->variant == 1 || p->variant == 2 || p->dbg) one_launch = false;  // measurement variants keep their own kernels
 #endif
@@ -1462,9 +1483,9 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
             unsigned *sy = s.d_sync + first * 128;
             return p->dtype == CAF_C128
                        ? surface_single_launch<double>(p, on, jin.src[0], dn, m_hay + first * in1, spec, ds, (uint64_t *)di, dv,
-                                                       (caf_peak *)dp, ho, sy, m_status, m_seq + first)
+                                                       (caf_peak *)dp, ho, sy, m_status, m_seq + first, two_nodes)
                        : surface_single_launch<float>(p, on, jin.src[0], dn, m_hay + first * in1, spec, ds, (uint64_t *)di, dv,
-                                                      (caf_peak *)dp, ho, sy, m_status, m_seq + first);
+                                                      (caf_peak *)dp, ho, sy, m_status, m_seq + first, two_nodes);
         }
         hipError_t e1 = hipSuccess;
         if (p->fused && p->variant != 2 && inb % 16 == 0) {  // the spectrum kernel stages the needles in itself

@@ -41,6 +41,7 @@ struct SurfArgs {
                            // atomics on another) = {ticket, needle blocks done, spectrum chains done, rows done}; zero between launches
     unsigned *status;      // device word: set non-zero if a wait ran into its bound (results of that launch are invalid)
     unsigned copy_blocks;  // workgroups that stage the needle (FusedArgs::stage_*); 0 = the needle is already at FusedArgs::sig
+    unsigned prep_blocks;  // 2 = this launch computes the haystack spectrum itself; 0 = a k_seq_prepare node in front of it did
     const double *freqs;   // [rows]
     int64_t row_base;      // global list position of row 0 (row shards)
     caf_peak *peak;        // device record
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_surf
     const unsigned role = ticket - S.copy_blocks;
 
     // ---- role 2: haystack spectrum of one chain (same arithmetic as k_seq_prepare) -----------------
-    if (role < 2u) {
+    if (role < S.prep_blocks) {
         const int chain = (int)role;
         const C *__restrict__ ph = phasor + (size_t)A.rows * 64;  // the f = 0 row
         const T inv = T(1.0 / 8192.0);
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_surf
     }
 
     // ---- role 3: one Doppler row -----------------------------------------------------------------------
-    const int r = (int)role - 2;  // < A.rows by construction of the grid
+    const int r = (int)(role - S.prep_blocks);  // < A.rows by construction of the grid
     if (r >= A.rows) return;
     const C th = A.tab.th[L.t];
     const C cfac = conj(th);
@@ -200,9 +201,9 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_surf
     // (spectrum ready by then) the wait costs nothing, not even the round trip of one poll; otherwise every
     // wave polls for itself (no barrier inside the chain)
     bool okh = true;
-    const unsigned h_early = __hip_atomic_load(&S.sync[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned h_early = S.prep_blocks ? __hip_atomic_load(&S.sync[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     seq_chain<T, 0, 0, PF>(e, a, rs_sig, rs_spec, pb, th, ph + 32, tw, twB, Lc, L, st, [&]() {
-        if (__builtin_amdgcn_readfirstlane(h_early) < 2u) okh = surf_wait(&S.sync[64], 2u);
+        if (__builtin_amdgcn_readfirstlane(h_early) < S.prep_blocks) okh = surf_wait(&S.sync[64], S.prep_blocks);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     });

@@ -201,11 +201,18 @@ int caf_stream_create(caf_plan *plan, size_t batch, int nslots, int want_surface
  * is private ("fused4096", "chain"), in series otherwise.  One replay then retires `batch`
  * surfaces at single-surface granularity; host buffers and results are laid out as in the
  * batched mode.
- * Single-surface chains (batch == 1, or CAF_STREAM_SPLIT) of "fused4096" plans are ONE kernel
- * node: needle staging, haystack spectrum, Doppler rows and find_peak run as roles of one launch
- * (csrc/kernels_surf4096.hpp).  CAF_STREAM_THREE_KERNELS keeps the three-node form {spectrum,
- * rows, find_peak} for comparison. */
-enum caf_stream_flags { CAF_STREAM_SPLIT = 1, CAF_STREAM_THREE_KERNELS = 2 };
+ * Single-surface chains (batch == 1, or CAF_STREAM_SPLIT) of "fused4096" plans run as roles of ONE
+ * launch (csrc/kernels_surf4096.hpp: needle staging, haystack spectrum, Doppler rows, find_peak) when
+ * at most two surfaces are in flight (nslots * chains per slot <= 2), and as TWO kernel nodes
+ * {staging + spectrum | rows + find_peak} otherwise; CAF_STREAM_ONE_KERNEL / CAF_STREAM_TWO_KERNELS
+ * force either, CAF_STREAM_THREE_KERNELS keeps the older {spectrum, rows, find_peak} chain (for
+ * comparison).  In the first two forms completion is read from a pinned sequence word. */
+enum caf_stream_flags {
+    CAF_STREAM_SPLIT = 1,
+    CAF_STREAM_THREE_KERNELS = 2,
+    CAF_STREAM_TWO_KERNELS = 4,
+    CAF_STREAM_ONE_KERNEL = 8
+};
 int caf_stream_create_ex(caf_plan *plan, size_t batch, int nslots, int want_surface, unsigned flags,
                          caf_stream **out);
 int caf_stream_destroy(caf_stream *st);

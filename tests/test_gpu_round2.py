@@ -396,8 +396,9 @@ def test_streaming_split_mode_parity(dtype, eng, oracle):
         assert np.max(np.abs(rv.astype(np.float64) - rvb.astype(np.float64))) <= (1e-13 if dtype == "c128" else 1e-5) * ov.max()
 
 
-@pytest.mark.parametrize("dtype,nrows", [("c128", 400), ("c64", 400), ("c128", 1), ("c128", 1300), ("c64", 37)])
-def test_stream_single_launch_surface(dtype, nrows, eng, oracle):
+@pytest.mark.parametrize("dtype,nrows,form", [("c128", 400, "one"), ("c64", 400, "one"), ("c128", 1, "one"), ("c128", 1300, "one"),
+                                              ("c64", 37, "one"), ("c128", 400, "two"), ("c64", 400, "two"), ("c128", 1300, "two")])
+def test_stream_single_launch_surface(dtype, nrows, form, eng, oracle):
     """Single-surface streaming chains of the n = 4096 path are ONE launch (k_seq_surface: needle staging,
     haystack spectrum, rows and find_peak as ordered-ticket roles of one grid).  Against the three-node form
     {k_seq_prepare, row kernel, k_peak} and the oracle: complex128 argmax indices and caf_peak records
@@ -405,7 +406,9 @@ def test_stream_single_launch_surface(dtype, nrows, eng, oracle):
     instantiation: the compiler contracts a*b+c differently in places); complex64 runs k_seq_rows'
     arithmetic instead of k_duo_rows' and is held to the oracle tolerance.  Twelve replays over two slots check that the launch
     re-arms its own counters; 1300 rows exceed the resident workgroup slots (later tickets start as earlier
-    ones retire), 1 row and 37 rows are the small ends."""
+    ones retire), 1 row and 37 rows are the small ends.  form "two": the same kernel behind a k_seq_prepare
+    node (staging + spectrum), i.e. rows + find_peak only -- what slots with more than two surfaces in
+    flight use."""
     import torch
     import caf_cookoff_amd as caf
     fr = np.linspace(-100.0, 100.0, nrows, endpoint=False) if nrows > 1 else np.array([12.5])
@@ -415,7 +418,8 @@ def test_stream_single_launch_surface(dtype, nrows, eng, oracle):
     plan = eng.plan(4096, fr, FS, dtype=dtype)
     res = {}
     for three in (False, True):
-        st = caf.Stream(plan, batch=1, nslots=2, want_surface=True, three_kernels=three)
+        st = caf.Stream(plan, batch=1, nslots=2, want_surface=True, three_kernels=three, one_kernel=form == "one" and not three,
+                        two_kernels=form == "two" and not three)
         out = []
         pending = []
         for step in range(12):
