@@ -108,11 +108,25 @@ def algorithmic_bytes(n_surfaces: int, rows_local: int, n: int, dtype: str) -> i
     return n_surfaces * per_surface + rows_local * 8
 
 
-def kernel_source_hash() -> str:
-    """sha256 over the kernel sources (csrc/*.hpp: every __global__ function lives there; caf_api.hip is
-    host code): ties a profiles/*/traffic.json to the kernels it measured."""
+_KERNEL_HEADERS = {  # the headers a row kernel's code comes from (everything else in csrc/ cannot change it)
+    "k_seq_rows": ("cplx.hpp", "kernels_fused4096.hpp", "kernels_seq4096.hpp"),
+    "k_duo_rows": ("cplx.hpp", "kernels_fused4096.hpp", "kernels_seq4096.hpp", "kernels_duo4096.hpp"),
+    "k_chain_rows": ("cplx.hpp", "kernels_fused4096.hpp", "kernels_seq4096.hpp", "kernels_chain.hpp"),
+}
+
+
+def kernel_source_hash(kernel_name: str = "") -> str:
+    """sha256 over the sources of one kernel (the csrc/*.hpp it is written in; every __global__ function
+    lives in a header, caf_api.hip is host code; unknown kernels: all headers): ties a
+    profiles/*/traffic.json to the code it measured."""
+    files = None
+    for key, names in _KERNEL_HEADERS.items():
+        if key in kernel_name:
+            files = [ROOT / "caf_cookoff_amd" / "csrc" / n for n in names]
+    if files is None:
+        files = sorted((ROOT / "caf_cookoff_amd" / "csrc").glob("*.hpp"))
     h = hashlib.sha256()
-    for f in sorted((ROOT / "caf_cookoff_amd" / "csrc").glob("*.hpp")):
+    for f in files:
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
@@ -123,7 +137,7 @@ def profiled_traffic(kernel_name: str, nsurf: int, dtype: str):
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command in separate passes, corrected as
     MI355X_MICROARCH.md prescribes; tools/profile_pack.py).  Collected offline, so it is only
     reported when the profile's kernel-source hash equals the running code's; otherwise null."""
-    here = kernel_source_hash()
+    here = kernel_source_hash(kernel_name)
     best, stale = None, None
     for f in sorted((ROOT / "profiles").glob("*/traffic.json")):
         try:
@@ -547,7 +561,7 @@ def main():
                        "surfaces_per_step": nsurf, "batch_per_gpu": args.batch,
                        "rows_per_gpu": rows, "parallelism": f"doppler-row-shard x{world}" if world > 1 else "single",
                        "kernel_path": plan.path, "device": devname, "cus": cu,
-                       "devices_visible_per_rank": ndev, "kernel_source_hash": kernel_source_hash()},
+                       "devices_visible_per_rank": ndev, "kernel_source_hash": kernel_source_hash(plan.kernel_name)},
             "roofline": roof,
         }
     # ---- live FP64-VALU ceiling of the shipped instruction stream (headline shape only) ----
