@@ -258,7 +258,14 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_surf
         for (int w = 1; w < 4; ++w) arg_merge(rb, ri, sv[w], si[w]);
         store_vec_aux<CAF_AUX_SC1>(rs_ri, (unsigned)(r * sizeof(uint64_t)), caf_v2u{ri, 0u});
         store_one_aux<CAF_AUX_SC1>(rs_rv, (unsigned)(r * sizeof(T)), 0u, rb);
-        if (S.h_peak) { S.h_ridx[r] = ri; S.h_rval[r] = rb; }
+        if (S.h_peak) {
+            // SYSTEM-scope stores (sc0 sc1): only for those does the s_waitcnt below mean "visible to the host".
+            // Plain stores to the pinned buffers are acknowledged early; a soak of 10^5 surfaces then showed
+            // 1-3 surfaces whose row words reached the host AFTER the sequence word of the last row
+            // (tools/stream_soak.py).
+            __hip_atomic_store(&S.h_ridx[r], (uint64_t)ri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&S.h_rval[r], rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (!(ok && okh)) *(volatile unsigned *)S.status = 1u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this row's peak is in memory before it is counted
         sh[1] = __hip_atomic_fetch_add(&S.sync[96], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
