@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Minimal single-surface streaming loop (for rocprofv3 --kernel-trace): usage stream_min.py [steps] [nslots] [three]"""
+"""Minimal single-surface streaming loop (for rocprofv3 --kernel-trace): usage stream_min.py [steps] [nslots] [three|auto] [c128|c64]"""
 import sys
 import time
 from pathlib import Path
@@ -11,9 +11,11 @@ from caf_cookoff_amd.synth import make_batch  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 nslots = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 three = len(sys.argv) > 3 and sys.argv[3] == "three"
+dtype = sys.argv[4] if len(sys.argv) > 4 else "c128"
 eng = caf.Engine(0)
-plan = eng.plan(4096, caf.bench_shifts(), 48000)
-nd, hs, lags, _ = make_batch(16, 4096, 48000, seed0=5000)
+import numpy as np  # noqa: E402
+plan = eng.plan(4096, caf.bench_shifts(), 48000, dtype=dtype)
+nd, hs, lags, _ = make_batch(16, 4096, 48000, seed0=5000, dtype=np.complex128 if dtype == "c128" else np.complex64)
 st = caf.Stream(plan, batch=1, nslots=nslots, want_surface=True, three_kernels=three)
 bufs = [st.buffers(s) for s in range(nslots)]
 for rep in range(2):
