@@ -192,6 +192,14 @@ __global__ void k_view(const T *__restrict__ surf, size_t L, size_t width, size_
     out[r * width + i] = sqrt(surf[r * L + src]);
 }
 
+// Probe pair for "do these two HIP streams run concurrently?" (caf_api.hip: streams_overlap): a bounded
+// ~0.2 ms idle loop on one stream, an empty kernel on the other.
+__global__ void k_idle(unsigned iters)
+{
+    for (unsigned i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(127);
+}
+__global__ void k_empty() {}
+
 // Streaming stage-in / stage-out (caf_stream_*): up to three (src, dst, bytes) jobs copied by ONE
 // kernel node of the slot's graph.  One side of every job is PINNED HOST memory mapped into the
 // device address space (hipHostMalloc is coherent: device accesses are uncached), so the two

@@ -182,8 +182,9 @@ int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, 
  * pinned results through their device mappings (the haystack is read in place, the needle is
  * staged into device memory by the spectrum launch, find_peak writes the row peaks and the
  * caf_peak records out) -- no copy-engine nodes.  While slot k computes, the caller fills slot
- * k+1's pinned buffers and submits it: its input transfer overlaps slot k's kernels.  Three
- * slots sustain the most single-surface replays per second on MI355X.  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
+ * k+1's pinned buffers and submits it: its input transfer overlaps slot k's kernels.  Three or
+ * four slots sustain the most single-surface replays per second on MI355X (the
+ * slot streams are probed at creation so that they sit on separate hardware queues).  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
  * only (tau, f) + per-row peaks come back, as SURVEY.md section 8d prescribes.
  * Plans whose row kernel keeps its intermediate data on-chip ("fused4096", "chain") give
  * every slot private device state, so slots execute concurrently.  Plans on the
