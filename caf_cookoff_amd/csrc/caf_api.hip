@@ -973,6 +973,7 @@ static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_ha
             case 16: k_chain_rows<T, 14, 4, 1, 16><<<grid, W, 0, c->stream>>>(a, phasor); break;
             case 30: k_chain_rows<T, 14, 4, 1, 30><<<grid, W, 0, c->stream>>>(a, phasor); break;
             case 31: k_chain_rows<T, 14, 4, 1, 31><<<grid, W, 0, c->stream>>>(a, phasor); break;
+            case 256: k_chain_rows<T, 14, 4, 1, 256><<<grid, W, 0, c->stream>>>(a, phasor); break;  // looped row (correct results)
             case 32: k_chain_rows<T, 14, 4, 1, 32><<<grid, W, 0, c->stream>>>(a, phasor); break;  // wave priorities by SIMD slot (correct results)
             case 64: k_chain_rows<T, 14, 4, 1, 64><<<grid, W, 0, c->stream>>>(a, phasor); break;  // wave priorities by wave % 4 (correct results)
             case 159: k_chain_rows<T, 14, 4, 1, 159><<<grid, W, 0, c->stream>>>(a, phasor); break;  // arithmetic only

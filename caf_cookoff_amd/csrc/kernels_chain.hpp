@@ -430,7 +430,11 @@ __device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[
     const C *psA = ph + 48 + 16 * rA, *psB = ph + 48 + 16 * rB;
     const unsigned voff = (unsigned)(beta * sizeof(C));
     C k1 = C{T(1), T(0)}, k2 = k1, k3 = k1;
-    if constexpr (R == 4) k1 = ph[112];  // w^M
+    constexpr bool RT = (ABL & 256) != 0;  // rA is a run-time value (looped R = 4 rows, measurement variant)
+    if constexpr (R == 4) {
+        k1 = ph[112];  // w^M
+        if constexpr (RT) { if (rA) k1 = C{k1.y, -k1.x}; }  // b = (-i)^rA w^M a1: x_rA = a0 + b, x_(rA+2) = a0 - b
+    }
     if constexpr (R == 8) {              // kappa_{rA, 1..3}
         k1 = ph[176 + 3 * rA];
         k2 = ph[176 + 3 * rA + 1];
@@ -465,9 +469,13 @@ __device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[
                 vB[q] = cmul_conj(x, psB[q]);
             } else if constexpr (R == 4) {
                 const C b = cmul(a[grp & 1][u][1], k1);
-                // rA = 0: x +- b;  rA = 1: x -+ i b
-                vA[q] = cmul_conj(rA == 0 ? x + b : sub_i(x, b), psA[q]);
-                vB[q] = cmul_conj(rA == 0 ? x - b : add_i(x, b), psB[q]);
+                if constexpr (RT) {
+                    vA[q] = cmul_conj(x + b, psA[q]);
+                    vB[q] = cmul_conj(x - b, psB[q]);
+                } else {  // rA = 0: x +- b;  rA = 1: x -+ i b
+                    vA[q] = cmul_conj(rA == 0 ? x + b : sub_i(x, b), psA[q]);
+                    vB[q] = cmul_conj(rA == 0 ? x - b : add_i(x, b), psB[q]);
+                }
             } else {
                 // x_rA = E + O, x_(rA+4) = E - O;  E = a0 + kappa_2 a2,  O = kappa_1 a1 + kappa_3 a3
                 const C E = cfma(x, a[grp & 1][u][2], k2);
@@ -599,10 +607,14 @@ __device__ __forceinline__ void chain_run(cpx<T> (&v)[NB][16], const ChainLane<T
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (r) {
+    if constexpr (R != 8 && !(ABL & 256)) {  // r is a compile-time constant after inlining: chain 0 keeps its cheaper twiddle form
+        if (r) {
+            L.inverse(v, [&](int b, int k, C x) { const TwFold<T> fpost(L.tw[b], post[b]); return twA_k(x, k, L.tw[b], fpost); });
+        } else {
+            L.inverse(v, [&](int b, int k, C x) { return twA_k(x, k, L.tw[b]); });
+        }
+    } else {  // r is a run-time value in the looped rows: post = 1 for r = 0 is exact
         L.inverse(v, [&](int b, int k, C x) { const TwFold<T> fpost(L.tw[b], post[b]); return twA_k(x, k, L.tw[b], fpost); });
-    } else {
-        L.inverse(v, [&](int b, int k, C x) { return twA_k(x, k, L.tw[b]); });
     }
 }
 
@@ -710,7 +722,107 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
                 if constexpr (ABL & 4) { C x = C{T(i), T(arr)}; keep(x); return x; }
                 return bload(rs_slab, (unsigned)(L.beta[b] * sizeof(C)), (unsigned)((arr * 16 + i) * W * sizeof(C)), (C *)nullptr);
             };
-            if constexpr (R == 4) {
+            if constexpr (R == 8 || (ABL & 256) != 0) {
+                // LOOPED form (R = 8 always; R = 4 as a measurement variant, where it is 1-2 % slower than the unrolled
+                // form below; R = 8 gains 14 %: 2.10 vs 2.44 ms per 2048 x 131072 complex64 rows, 74 vs 206 spills): the R/2 chain pairs are iterations of a run-time loop and the two chains of a pair
+                // iterations of an inner one, so the chain code (input stage, forward, spectrum product, inverse:
+                // ~2.8 k instructions) exists once instead of R times.  Fully inlined the R = 4 row is ~90 KB of
+                // code and the R = 8 row ~180 KB, against a 64 KB instruction cache shared by two CUs.
+                static_assert(NB == 1, "looped rows are written for one butterfly per thread");
+                constexpr int NP = R / 2;
+                C cur[1][16], oth[1][16];
+#pragma clang loop unroll(disable)
+                for (int it = 0; it < NP; ++it) {
+                    // R = 8: z_r = W_128^(i r) y'_r.  Pairs (r', r'+4): P_r' = y'_r' + W_32^i y'_(r'+4), Q_r' = y'_r' - ...;
+                    //   lags m' + M j:  j = 2j'   : sum_r' (i)^(j' r') thP^r' P_r',  thP = W_128^i
+                    //                   j = 2j'+1 : sum_r' (i)^(j' r') thQ^r' Q_r',  thQ = W_128^(i+16)
+                    //   i.e. two radix-4 combinations like the R = 4 one.  Pair order 0, 2, 1, 3; slab arrays:
+                    //   [0],[1] = P0, Q0 -> aP, bP;  [2],[3] = aQ, bQ;  [4],[5] = P1, Q1;  P3, Q3 stay in registers.
+                    // R = 4: pairs 0, 1 as in the unrolled form below
+                    const int rp = __builtin_amdgcn_readfirstlane(R == 4 ? it : (((it & 1) << 1) | (it >> 1)));
+                    chain_input_pair<T, LOGM, R, ABL>(cur[0], oth[0], rs_sig, rp, rp + NP, L.beta[0], ph);
+#pragma clang loop unroll(disable)
+                    for (int c = 0; c < 2; ++c) {
+                        chain_run<T, LOGM, R, NB, ABL>(cur, L, A, rs_spec, __builtin_amdgcn_readfirstlane(rp + NP * c), pb);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { const C t = cur[0][i]; cur[0][i] = oth[0][i]; oth[0][i] = t; }
+                    }
+                    // cur = y'_rp, oth = y'_(rp + R/2)
+                    if constexpr (R == 4) {
+                        if (it == 0) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                C a, bb;
+                                bfly_w(cur[0][i], oth[0][i], W64C[2 * i], W64S[2 * i], a, bb);
+                                slab_st(0, i, 0, a);
+                                slab_st(1, i, 0, bb);
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                C cc, dd;
+                                bfly_w(cur[0][i], oth[0][i], W64C[2 * i], W64S[2 * i], cc, dd);
+                                const C a = slab_ld(0, i, 0), bb = slab_ld(1, i, 0);
+                                C c0, c2, c1, c3;
+                                bfly_w(a, cc, W64C[i], W64S[i], c0, c2);
+                                bfly_w(bb, dd, -W64S[i], W64C[i], c1, c3);
+                                emit(0, i, 0, c0);
+                                emit(1, i, 0, c1);
+                                emit(2, i, 0, c2);
+                                emit(3, i, 0, c3);
+                                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {  // P, Q in place of y'_r', y'_(r'+4)
+                            C P, Q;
+                            bfly_w(cur[0][i], oth[0][i], W32C16[i], W32S16[i], P, Q);
+                            cur[0][i] = P;
+                            oth[0][i] = Q;
+                        }
+                        if (it == 0) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) { slab_st(0, i, 0, cur[0][i]); slab_st(1, i, 0, oth[0][i]); }
+                        } else if (it == 1) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                C aP, bP, aQ, bQ;
+                                bfly_w(slab_ld(0, i, 0), cur[0][i], W128C[2 * i], W128S[2 * i], aP, bP);
+                                bfly_w(slab_ld(1, i, 0), oth[0][i], W128C[2 * i + 32], W128S[2 * i + 32], aQ, bQ);
+                                slab_st(0, i, 0, aP);
+                                slab_st(1, i, 0, bP);
+                                slab_st(2, i, 0, aQ);
+                                slab_st(3, i, 0, bQ);
+                                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                            }
+                        } else if (it == 2) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) { slab_st(4, i, 0, cur[0][i]); slab_st(5, i, 0, oth[0][i]); }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                C cc, dd, o0, o1, o2, o3;
+                                bfly_w(slab_ld(4, i, 0), cur[0][i], W128C[2 * i], W128S[2 * i], cc, dd);
+                                bfly_w(slab_ld(0, i, 0), cc, W128C[i], W128S[i], o0, o2);
+                                bfly_w(slab_ld(1, i, 0), dd, -W128S[i], W128C[i], o1, o3);
+                                emit(0, i, 0, o0);
+                                emit(2, i, 0, o1);
+                                emit(4, i, 0, o2);
+                                emit(6, i, 0, o3);
+                                bfly_w(slab_ld(5, i, 0), oth[0][i], W128C[2 * i + 32], W128S[2 * i + 32], cc, dd);
+                                bfly_w(slab_ld(2, i, 0), cc, W128C[i + 16], W128S[i + 16], o0, o2);
+                                bfly_w(slab_ld(3, i, 0), dd, -W128S[i + 16], W128C[i + 16], o1, o3);
+                                emit(1, i, 0, o0);
+                                emit(3, i, 0, o1);
+                                emit(5, i, 0, o2);
+                                emit(7, i, 0, o3);
+                                if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                }
+            } else if constexpr (R == 4) {
                 // z_r = W_64^(i r) y'_r;  a, b = z0 +- z2;  c, d = z1 +- z3 = W_64^i (y1' +- W_64^(2i) y3');
                 // c[m' + M j]: j = 0, 2: a +- c;  j = 1, 3: b +- i d
                 {
@@ -751,66 +863,6 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
                         emit(3, i, b, c3);
                     }
                     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four (a, b) pairs per slot in flight
-                }
-            } else {
-                // R = 8.  z_r = W_128^(i r) y'_r.  Pairs (r', r'+4): P_r' = y'_r' + W_32^i y'_(r'+4), Q_r' = y'_r' - ...;
-                // lags m' + M j:  j = 2j'   : sum_r' (i)^(j' r') thP^r' P_r',  thP = W_128^i
-                //                 j = 2j'+1 : sum_r' (i)^(j' r') thQ^r' Q_r',  thQ = W_128^(i+16)
-                // i.e. two radix-4 combinations like the R = 4 one.  Pair order 0, 2, 1, 3; slab arrays:
-                // [0],[1] = P0, Q0 -> aP, bP;  [2],[3] = aQ, bQ;  [4],[5] = P1, Q1;  P3, Q3 stay in registers.
-                static_assert(NB == 1, "R = 8 is written for one butterfly per thread");
-                C u[1][16], v[1][16];
-                auto run_pair = [&](int rp) {
-                    chain_input_pair<T, LOGM, R, ABL>(u[0], v[0], rs_sig, rp, rp + 4, L.beta[0], ph);
-                    chain_run<T, LOGM, R, NB, ABL>(u, L, A, rs_spec, rp, pb);
-                    chain_run<T, LOGM, R, NB, ABL>(v, L, A, rs_spec, rp + 4, pb);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {  // P, Q in place of y'_r', y'_(r'+4)
-                        C P, Q;
-                        bfly_w(u[0][i], v[0][i], W32C16[i], W32S16[i], P, Q);
-                        u[0][i] = P;
-                        v[0][i] = Q;
-                    }
-                };
-                run_pair(0);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { slab_st(0, i, 0, u[0][i]); slab_st(1, i, 0, v[0][i]); }
-                run_pair(2);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {  // a, b = X0 +- theta^2 X2
-                    C aP, bP, aQ, bQ;
-                    bfly_w(slab_ld(0, i, 0), u[0][i], W128C[2 * i], W128S[2 * i], aP, bP);
-                    bfly_w(slab_ld(1, i, 0), v[0][i], W128C[2 * i + 32], W128S[2 * i + 32], aQ, bQ);
-                    slab_st(0, i, 0, aP);
-                    slab_st(1, i, 0, bP);
-                    slab_st(2, i, 0, aQ);
-                    slab_st(3, i, 0, bQ);
-                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-                run_pair(1);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { slab_st(4, i, 0, u[0][i]); slab_st(5, i, 0, v[0][i]); }
-                run_pair(3);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    C cc, dd, o0, o1, o2, o3;
-                    // even lag blocks: theta = W_128^i
-                    bfly_w(slab_ld(4, i, 0), u[0][i], W128C[2 * i], W128S[2 * i], cc, dd);   // c', d' = P1 +- theta^2 P3
-                    bfly_w(slab_ld(0, i, 0), cc, W128C[i], W128S[i], o0, o2);               // aP +- theta c'
-                    bfly_w(slab_ld(1, i, 0), dd, -W128S[i], W128C[i], o1, o3);              // bP +- i theta d'
-                    emit(0, i, 0, o0);
-                    emit(2, i, 0, o1);
-                    emit(4, i, 0, o2);
-                    emit(6, i, 0, o3);
-                    // odd lag blocks: theta = W_128^(i+16)
-                    bfly_w(slab_ld(5, i, 0), v[0][i], W128C[2 * i + 32], W128S[2 * i + 32], cc, dd);
-                    bfly_w(slab_ld(2, i, 0), cc, W128C[i + 16], W128S[i + 16], o0, o2);
-                    bfly_w(slab_ld(3, i, 0), dd, -W128S[i + 16], W128C[i + 16], o1, o3);
-                    emit(1, i, 0, o0);
-                    emit(3, i, 0, o1);
-                    emit(5, i, 0, o2);
-                    emit(7, i, 0, o3);
-                    if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // at most two rows of slab values in flight
                 }
             }
         }

@@ -46,7 +46,7 @@ def test_chain_kernels_register_shape():
     VGPRs), and spills bounded -- the R = 2 instantiations run (almost) spill-free since the butterfly
     constants became SGPR operands; the R = 4 complex64 kernel (BASELINE configs[3]) sits at
     35 spilled registers (90 before the load/store optimizer was switched off for this kernel family) and
-    the R = 8 kernels (six live slab descriptors + the W_128 combine) at 131 / 186, known costs
+    the R = 8 kernels (six live slab descriptors + the W_128 combine; chain pairs as a run-time loop) at 59 / 74, known costs
      that must not get worse silently."""
     usage = _usage()
     seen = 0
@@ -58,6 +58,6 @@ def test_chain_kernels_register_shape():
         r = 8 if "ELi8ELi1ELi0E" in name else 4 if "ELi4ELi1ELi0E" in name else 2
         assert int(f["LDS Size [bytes/block]"]) <= 160 * 1024
         assert int(f["Occupancy [waves/SIMD]"]) == (2 if is_f64 else 4), name
-        limit = {2: 30, 4: 30 if is_f64 else 50, 8: 140 if is_f64 else 200}[r]
+        limit = {2: 30, 4: 30 if is_f64 else 50, 8: 70 if is_f64 else 90}[r]
         assert int(f["VGPRs Spill"]) <= limit, (name, f["VGPRs Spill"])
     assert seen == 11  # 5 complex128 + 6 complex64 instantiations
