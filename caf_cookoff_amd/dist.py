@@ -41,16 +41,17 @@ def decode_key(key: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def reduce_global_peak(val: torch.Tensor, row: torch.Tensor, idx: torch.Tensor,
-                       group: Optional[dist.ProcessGroup] = None, method: str = "allgather"
-                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                       group: Optional[dist.ProcessGroup] = None, method: str = "allgather",
+                       always_collective: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Combine per-rank shard peaks into the global find_peak result.
 
     val/row/idx: [batch] local peak value (float64), GLOBAL row position (-1 = no peak)
     and lag index of this rank's shard (the caf_peak records of caf_surface_dev).
     Returns (gmax, grow, gidx), identical on every rank.  Works on CPU (gloo) and GPU
-    (nccl/RCCL) tensors; without an initialised process group it is the identity."""
+    (nccl/RCCL) tensors; without an initialised process group it is the identity, and so it is in a
+    group of one unless `always_collective` (tests: runs the RCCL calls on a single GPU)."""
     val = val.to(torch.float64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always_collective):
         has = row >= 0
         return (torch.where(has, val, torch.zeros_like(val)), torch.where(has, row, torch.full_like(row, -1)),
                 torch.where(has, idx, torch.zeros_like(idx)))

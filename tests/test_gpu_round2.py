@@ -620,3 +620,39 @@ def test_chain_path_edge_shapes(eng, oracle):
         pk = d_p.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[:, 0]
         assert int(pk[0]["idx"]) == 11 and int(pk[0]["row"]) == 1 and int(pk[5]["row"]) == -1
         assert int(d_i[699, 0]) == 11
+
+
+def test_peak_reduction_through_rccl_single_rank():
+    """The global-peak exchange of the row-sharded multi-GPU path (dist.reduce_global_peak) through the REAL
+    RCCL backend, in a group of one rank on this GPU (a child process: the process group must not leak into
+    the test process): int64 bit-pattern all_gather and the MAX / MIN-key all_reduce form on device tensors,
+    ties, a surface without a peak -- equal to the identity.  (More ranks cannot share one GPU under RCCL;
+    the N-rank logic is covered on gloo in tests/test_dist_gloo.py.)"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29653")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+from caf_cookoff_amd.dist import reduce_global_peak
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+val = torch.tensor([3.5, 0.0, 7.25, 7.25], dtype=torch.float64, device="cuda")
+row = torch.tensor([12, -1, 399, 0], dtype=torch.int64, device="cuda")
+idx = torch.tensor([202, 0, 8191, 70], dtype=torch.int64, device="cuda")
+for method in ("allgather", "allreduce"):
+    g, r, i = reduce_global_peak(val, row, idx, method=method, always_collective=True)
+    torch.cuda.synchronize()
+    assert g.tolist() == [3.5, 0.0, 7.25, 7.25], (method, g)
+    assert r.tolist() == [12, -1, 399, 0] and i.tolist() == [202, 0, 8191, 70], (method, r, i)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+""" % str(root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout + r.stderr
+
