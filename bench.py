@@ -223,10 +223,11 @@ class Case:
         self.peak = torch.empty((batch, 4), dtype=torch.float64, device=dev)  # caf_peak records (32 B)
         self.peak_i = self.peak.view(torch.int64)
 
-    def launch(self, plan=None):
+    def launch(self, plan=None, peak=None):
         (plan or self.plan).surface_dev(self.nd.data_ptr(), self.hs.data_ptr(), self.batch,
                                         self.surf.data_ptr() if self.surf is not None else None,
-                                        self.ridx.data_ptr(), self.rval.data_ptr(), self.peak.data_ptr())
+                                        self.ridx.data_ptr(), self.rval.data_ptr(),
+                                        (self.peak if peak is None else peak).data_ptr())
 
     def host_peaks(self):
         import numpy as np
@@ -444,6 +445,10 @@ def main():
     # Rehearsal mode for a one-GPU box (never used by the driver): every rank shares cuda:0 and
     # the peak reduction runs over gloo on CPU copies; everything else is the N>1 code path.
     rehearse = os.environ.get("CAF_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    # CAF_BENCH_FORCE_COLLECTIVES=1 (under torchrun with ONE rank): take every collective of the N > 1 path
+    # through the real RCCL backend on this one GPU (process group, device-count check, barriers, the peak
+    # exchange, the max-over-ranks clock) -- the closest a one-GPU box gets to the driver's --gpus 8 run
+    coll = world > 1 or (os.environ.get("CAF_BENCH_FORCE_COLLECTIVES") == "1" and "WORLD_SIZE" in os.environ)
     ndev = torch.cuda.device_count()
     if rehearse:
         local_rank = 0
@@ -451,7 +456,7 @@ def main():
         sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {ndev} device(s) are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo")
@@ -462,7 +467,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if not rehearse and int(t.item()) < world:
             sys.exit(f"bench.py: a rank sees only {int(t.item())} device(s) for a {world}-GPU run")
-    n_gpus_seen = dist.get_world_size() if world > 1 else 1
+    n_gpus_seen = dist.get_world_size() if coll else 1
 
     eng = caf.Engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -477,26 +482,52 @@ def main():
     case = Case(eng, torch, dev, n_samp, freqs, args.dtype, nsurf, lo, hi)
     plan = case.plan
 
+    # find_peak across the row shards (dist.reduce_global_peak: one RCCL all_gather of 16 B per surface and
+    # rank + a local reduction), OVERLAPPED with the next step's kernels: it runs on a side stream behind an
+    # event recorded after this step's find_peak kernel, on alternating caf_peak buffers; the main stream
+    # waits for a buffer's previous exchange before the kernels write it again.  (On the main stream the
+    # exchange is ~0.1 ms of a 3.9 ms step during which the chip idles: 63.7 k vs 65.5 k surfaces/s.)
+    peaks = [case.peak, torch.empty_like(case.peak)] if coll else [case.peak]
+    side = torch.cuda.Stream(device=dev) if coll and not rehearse else None
+    ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+    used = [False, False]
+    nstep = [0]
+
     def step():
-        case.launch()
-        if world == 1:
+        if not coll:
+            case.launch()
             return None
-        # find_peak across the row shards: RCCL all-reduce(max) + all-reduce(min) on 8 B per surface
+        k = nstep[0] & 1
+        nstep[0] += 1
+        pk = peaks[k]
         if rehearse:
-            pk_c = case.peak.cpu()
+            case.launch(peak=pk)
+            pk_c = pk.cpu()
             pk_ci = pk_c.view(torch.int64)
-            return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2], method=args.peak_reduce)
-        return reduce_global_peak(case.peak[:, 0], case.peak_i[:, 3], case.peak_i[:, 2], method=args.peak_reduce)
+            return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2], method=args.peak_reduce, always_collective=True)
+        main = torch.cuda.current_stream()
+        if used[k]:
+            main.wait_event(ev_done[k])
+        case.launch(peak=pk)
+        ev_ready[k].record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_ready[k])
+            pki = pk.view(torch.int64)
+            out = reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=args.peak_reduce, always_collective=True)
+            ev_done[k].record(side)
+        used[k] = True
+        return out
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
             torch.cuda.synchronize()
 
     def allreduce_max_time(seconds: float) -> float:
         t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if rehearse else dev)
-        if world > 1:
+        if coll:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -510,7 +541,7 @@ def main():
         if args.warmup == 0:
             out = step()
         torch.cuda.synchronize()
-        if world == 1:
+        if not coll:
             g_idx, g_freq, _ = case.host_peaks()
         else:
             gmax, grow, gidx = out
@@ -526,7 +557,7 @@ def main():
     for _ in range(K):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if coll:
         dist.barrier()
         torch.cuda.synchronize()
     el = time.perf_counter() - t0
@@ -622,7 +653,7 @@ def main():
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
     eng.close()
-    if world > 1:
+    if coll:
         dist.barrier()
         dist.destroy_process_group()
 
