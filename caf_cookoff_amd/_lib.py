@@ -70,6 +70,10 @@ SYMBOLS = [
     ("caf_xcor_c64", _int, [_vp, _fp, _fp, _sz, _fp]),
     ("caf_surface_c128", _int, [_vp, _dp, _dp, _sz, _dp, _sz, _u32, _dp, _up, _dp, _pp]),
     ("caf_surface_c64", _int, [_vp, _fp, _fp, _sz, _dp, _sz, _u32, _fp, _up, _fp, _pp]),
+    ("caf_host_alloc", _int, [_vp, _sz, ctypes.POINTER(_vp)]),
+    ("caf_host_free", _int, [_vp, _vp]),
+    ("caf_host_register", _int, [_vp, _vp, _sz]),
+    ("caf_host_unregister", _int, [_vp, _vp]),
     ("caf_find_peak", _int, [_vp, _dp, _up, _dp, _sz, _pp]),
     ("caf_plan_create", _int, [_vp, _sz, _dp, _sz, _u32, _int, _sz, _sz, ctypes.POINTER(_vp)]),
     ("caf_plan_destroy", _int, [_vp]),

@@ -8,8 +8,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -86,6 +88,54 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Pinned host memory for everything a kernel and the host both touch (staging buffers, result words,
+// sequence / status words): explicitly coherent (fine-grained) and mapped, not "whatever the runtime's
+// default is" -- the kernels read and write it in place and the host polls it.
+static hipError_t pinned_alloc(void **p, size_t bytes)
+{
+    return hipHostMalloc(p, bytes, hipHostMallocCoherent | hipHostMallocMapped);
+}
+
+// a pinned staging buffer of the host-pointer entry points and its device mapping (grows, never shrinks)
+struct PinBuf {
+    void *h = nullptr, *m = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return CAF_OK;
+        release();
+        hipError_t e = pinned_alloc(&h, bytes);
+        if (e != hipSuccess) { h = nullptr; return fail(CAF_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+        e = hipHostGetDevicePointer(&m, h, 0);
+        if (e != hipSuccess) { (void)hipHostFree(h); h = nullptr; return fail(CAF_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+        cap = bytes;
+        return CAF_OK;
+    }
+    void release() { if (h) (void)hipHostFree(h); h = m = nullptr; cap = 0; }
+};
+
+// One cached (n, freq list, fs, dtype) of the host-pointer caf_surface_* entry points: its plan (what
+// Xcor::new buys, xcor_rustfft.rs:29-46) plus one slot of pinned staging, device buffers and counters --
+// the machinery of a caf_stream slot, launched directly instead of through a graph.  A context keeps the
+// four most recently used.
+struct HostSlot {
+    caf_plan *plan = nullptr;
+    std::vector<double> freqs;
+    unsigned long long stamp = 0;  // LRU clock
+    bool one_launch = false;       // n = 4096: the whole surface is ONE launch (k_seq_surface), completion is a polled word
+    char *h_base = nullptr, *m_base = nullptr;  // one pinned allocation: needle | haystack | peak | row_idx | row_val | status | seq
+    size_t o_hay = 0, o_peak = 0, o_ridx = 0, o_rval = 0, o_status = 0, o_seq = 0;
+    void *d_needle = nullptr, *d_ridx = nullptr, *d_rval = nullptr, *d_peak = nullptr, *d_spec = nullptr, *d_slab = nullptr;
+    unsigned *d_sync = nullptr;
+    unsigned long long launches = 0;
+};
+
+struct HostRange {  // caller memory this context may write in place (caf_host_alloc / caf_host_register)
+    size_t bytes = 0;
+    char *dev = nullptr;
+    bool owned = false;
+};
+
 struct caf_ctx {
     int device = 0;
     int cu_count = 0;
@@ -102,10 +152,12 @@ struct caf_ctx {
     std::map<std::pair<size_t, int>, void *> tw_cache;
     // chain-path tables per (LOGM, R, dtype): {twM, th}
     std::map<std::tuple<int, int, int>, std::pair<void *, void *>> chain_tabs;
-    // host-API staging + cached plan
-    DevBuf io_needle, io_hay, io_surface, io_ridx, io_rval, io_peak, io_a, io_b;
-    caf_plan *cached = nullptr;
-    std::vector<double> cached_freqs;
+    // host-pointer entry points: cached plans + their staging slots (LRU), shared work buffers
+    std::vector<HostSlot *> host_slots;
+    unsigned long long host_clock = 0;
+    DevBuf io_surface, io_a, io_b;
+    PinBuf pin_a, pin_b;
+    std::map<char *, HostRange> host_ranges;
     std::vector<caf_plan *> plans;  // every live plan of this context (destroyed with it)
     // Streams of caf_stream slots are pooled per context and reused by later caf_stream objects: how
     // the runtime spreads streams over its few hardware queues depends on creation order, and a slot
@@ -238,6 +290,7 @@ extern "C" int caf_ctx_create(int device_id, caf_ctx **out)
 }
 
 extern "C" int caf_plan_destroy(caf_plan *p);
+static void host_slot_free(HostSlot *s);
 
 extern "C" int caf_ctx_destroy(caf_ctx *c)
 {
@@ -248,6 +301,7 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
                         p->live_streams);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    while (!c->host_slots.empty()) { host_slot_free(c->host_slots.back()); c->host_slots.pop_back(); }
     while (!c->plans.empty()) caf_plan_destroy(c->plans.back());  // user plans too: their tables live in this context
     for (int d = 0; d < 2; ++d) {
         if (c->tw4096[d]) (void)hipFree(c->tw4096[d]);
@@ -262,9 +316,12 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
         if (st_ != c->own_stream) (void)hipStreamDestroy(st_);
     for (auto &kv : c->tw_cache) (void)hipFree(kv.second);
     for (auto &kv : c->chain_tabs) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.second); }
-    c->io_needle.release(); c->io_hay.release(); c->io_surface.release();
-    c->io_ridx.release(); c->io_rval.release(); c->io_peak.release();
-    c->io_a.release(); c->io_b.release();
+    c->io_surface.release(); c->io_a.release(); c->io_b.release();
+    c->pin_a.release(); c->pin_b.release();
+    for (auto &kv : c->host_ranges) {
+        if (kv.second.owned) (void)hipHostFree(kv.first);
+        else (void)hipHostUnregister(kv.first);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return CAF_OK;
@@ -316,18 +373,20 @@ static int apply_shift_impl(caf_ctx *c, const T *in, size_t n, double f, uint32_
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = n * sizeof(cpx<T>);
     int rc;
-    if ((rc = c->io_a.ensure(bytes))) return rc;
-    if ((rc = c->io_b.ensure(bytes))) return rc;
+    if ((rc = c->pin_a.ensure(bytes))) return rc;
+    if ((rc = c->pin_b.ensure(bytes))) return rc;
     // same left-to-right f64 evaluation as mod.rs:54-56 (host IEEE arithmetic)
     const double dt = 1.0 / (double)fs;
     volatile double two_pi_f = (2.0 * 3.14159265358979323846264338327950288) * f;
     const double ph = two_pi_f * dt;
-    HIPCHK(hipMemcpyAsync(c->io_a.p, in, bytes, hipMemcpyHostToDevice, c->stream));
-    k_apply_shift<T><<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>((const cpx<T> *)c->io_a.p, n, ph,
-                                                                         (cpx<T> *)c->io_b.p);
+    // the kernel reads the pinned copy of `in` and writes the pinned result in place (one pass over PCIe each
+    // way, no copy-engine hop and no pageable hipMemcpyAsync: 64 KiB each way at n = 4096)
+    memcpy(c->pin_a.h, in, bytes);
+    k_apply_shift<T><<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>((const cpx<T> *)c->pin_a.m, n, ph,
+                                                                         (cpx<T> *)c->pin_b.m);
     KCHK();
-    HIPCHK(hipMemcpyAsync(out, c->io_b.p, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(out, c->pin_b.h, bytes);
     return CAF_OK;
 }
 
@@ -353,11 +412,17 @@ static int xcor_impl(caf_ctx *c, const T *a, const T *b, size_t n, T *out, int d
     int rc;
     if ((rc = c->io_a.ensure(2 * bytes))) return rc;
     if ((rc = c->io_b.ensure(2 * bytes))) return rc;
+    if ((rc = c->pin_a.ensure(2 * bytes))) return rc;
+    if ((rc = c->pin_b.ensure(bytes))) return rc;
     void *tw = nullptr;
     if ((rc = get_generic_tw<T>(c, n, dt, &tw))) return rc;
     cpx<T> *x = (cpx<T> *)c->io_a.p, *y = (cpx<T> *)c->io_b.p;
-    HIPCHK(hipMemcpyAsync(x, a, bytes, hipMemcpyHostToDevice, c->stream));      // row 0 = a
-    HIPCHK(hipMemcpyAsync(x + n, b, bytes, hipMemcpyHostToDevice, c->stream));  // row 1 = b
+    memcpy(c->pin_a.h, a, bytes);                  // row 0 = a
+    memcpy((char *)c->pin_a.h + bytes, b, bytes);  // row 1 = b
+    const size_t in16 = (2 * bytes / 16 + 255) / 256;
+    const unsigned cgrid = (unsigned)(in16 < 1 ? 1 : in16 > 1024 ? 1024 : in16);
+    k_stage_copy<<<cgrid, 256, 0, c->stream>>>(CopyJobs{{c->pin_a.m, nullptr, nullptr}, {x, nullptr, nullptr}, {2 * bytes, 0, 0}});
+    KCHK();
     cpx<T> *spec = nullptr;
     if ((rc = run_fft<T>(c, x, y, (const cpx<T> *)tw, n, 2, 0, &spec))) return rc;  // xcor_rustfft.rs:58-61
     cpx<T> *other = spec == x ? y : x;
@@ -365,8 +430,10 @@ static int xcor_impl(caf_ctx *c, const T *a, const T *b, size_t n, T *out, int d
     KCHK();
     cpx<T> *res = nullptr;
     if ((rc = run_fft<T>(c, spec + n, other + n, (const cpx<T> *)tw, n, 1, 1, &res))) return rc;  // :76
-    HIPCHK(hipMemcpyAsync(out, res, bytes, hipMemcpyDeviceToHost, c->stream));
+    k_stage_copy<<<cgrid, 256, 0, c->stream>>>(CopyJobs{{res, nullptr, nullptr}, {c->pin_b.m, nullptr, nullptr}, {bytes, 0, 0}});
+    KCHK();
     HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(out, c->pin_b.h, bytes);
     return CAF_OK;
 }
 
@@ -597,7 +664,6 @@ extern "C" int caf_plan_destroy(caf_plan *p)
     p->bwork.release(); p->bhwork.release(); p->bpart_val.release(); p->bpart_idx.release();
     p->slab.release();
     for (auto ev : p->ev) (void)hipEventDestroy(ev);
-    if (p->ctx->cached == p) p->ctx->cached = nullptr;
     delete p;
     return CAF_OK;
 }
@@ -1153,22 +1219,134 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
 }
 
 // ----------------------------------------------------------- surface (host) --
-static int get_cached_plan(caf_ctx *c, size_t n, const double *freqs, size_t nfreq, uint32_t fs, int dtype,
-                           caf_plan **out)
+// The literal drop-in call: every caller of the reference does `X::caf_surface(..)` then `X::find_peak(..)`
+// with host slices (main.rs:25-26, tests/test.rs:25-26, benches/caf_bench.rs:39-40).  Built on the machinery of
+// the streaming slots: per cached (n, freq list, fs, dtype) a plan + pinned staging + device buffers; the inputs
+// are copied into the pinned buffers by the CPU (2 x 64 KiB: ~3 us) and read from there by the kernels, the row
+// peaks and the caf_peak record are written to pinned memory by the kernels themselves.  No pageable
+// hipMemcpyAsync, no allocation per call.  n = 4096: the whole surface is ONE direct launch of k_seq_surface
+// (needle staging, haystack spectrum, rows, find_peak as roles of one grid) whose completion the host reads
+// from a pinned sequence word.  A host surface is written IN PLACE by the row kernel when the caller's buffer
+// is memory this context may address (caf_host_alloc / caf_host_register: the stores cross PCIe while the
+// other rows compute), else into a context-owned device slab followed by one D2H copy.
+static void host_slot_free(HostSlot *s)
 {
-    caf_plan *p = c->cached;
-    if (p && p->n == n && p->fs == fs && p->dtype == dtype && p->nfreq_total == nfreq && p->row_begin == 0 &&
-        p->rows == nfreq && c->cached_freqs.size() == nfreq &&
-        (nfreq == 0 || memcmp(c->cached_freqs.data(), freqs, nfreq * sizeof(double)) == 0)) {
-        *out = p;
-        return CAF_OK;
+    if (!s) return;
+    if (s->plan) caf_plan_destroy(s->plan);
+    if (s->h_base) (void)hipHostFree(s->h_base);
+    for (void *p : {s->d_needle, s->d_ridx, s->d_rval, s->d_peak, s->d_spec, s->d_slab, (void *)s->d_sync})
+        if (p) (void)hipFree(p);
+    delete s;
+}
+
+static constexpr size_t HOST_SLOTS_MAX = 4;
+
+static int get_host_slot(caf_ctx *c, size_t n, const double *freqs, size_t nfreq, uint32_t fs, int dtype, HostSlot **out)
+{
+    for (HostSlot *s : c->host_slots) {
+        const caf_plan *p = s->plan;
+        if (p->n == n && p->fs == fs && p->dtype == dtype && p->nfreq_total == nfreq && s->freqs.size() == nfreq &&
+            (nfreq == 0 || memcmp(s->freqs.data(), freqs, nfreq * sizeof(double)) == 0)) {
+            s->stamp = ++c->host_clock;
+            *out = s;
+            return CAF_OK;
+        }
     }
-    if (p) { caf_plan_destroy(p); c->cached = nullptr; }
-    int rc = caf_plan_create(c, n, freqs, nfreq, fs, dtype, 0, nfreq, &p);
-    if (rc) return rc;
-    c->cached = p;
-    c->cached_freqs.assign(freqs, freqs + nfreq);
-    *out = p;
+    if (c->host_slots.size() >= HOST_SLOTS_MAX) {  // evict the least recently used
+        size_t lru = 0;
+        for (size_t i = 1; i < c->host_slots.size(); ++i)
+            if (c->host_slots[i]->stamp < c->host_slots[lru]->stamp) lru = i;
+        (void)hipStreamSynchronize(c->stream);
+        host_slot_free(c->host_slots[lru]);
+        c->host_slots.erase(c->host_slots.begin() + (long)lru);
+    }
+    HostSlot *s = new (std::nothrow) HostSlot;
+    if (!s) return fail(CAF_ERR_NOMEM, "out of host memory");
+    auto bail = [&](int code) { host_slot_free(s); return code; };
+    int rc = caf_plan_create(c, n, freqs, nfreq, fs, dtype, 0, nfreq, &s->plan);
+    if (rc) return bail(rc);
+    caf_plan *p = s->plan;
+    s->freqs.assign(freqs, freqs + nfreq);
+    s->one_launch = p->fused && p->rows > 0;
+#ifdef CAF_MEASURE
+    if (p->variant == 1 || p->variant == 2) s->one_launch = false;  // measurement variants keep their own kernels
+#endif
+    const size_t esz = elem_size(dtype), rsz = real_size(dtype), in1 = n * esz, rows = nfreq ? nfreq : 1;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    s->o_hay = up(in1);
+    s->o_peak = s->o_hay + up(in1);
+    s->o_ridx = s->o_peak + 256;
+    s->o_rval = s->o_ridx + up(rows * sizeof(uint64_t));
+    s->o_status = s->o_rval + up(rows * rsz);
+    s->o_seq = s->o_status + 256;
+    const size_t pin_bytes = s->o_seq + 256;
+#define HCHK(expr)                                                                                         \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess) return bail(fail(CAF_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__))); \
+    } while (0)
+    HCHK(pinned_alloc((void **)&s->h_base, pin_bytes));
+    memset(s->h_base, 0, pin_bytes);
+    HCHK(hipHostGetDevicePointer((void **)&s->m_base, s->h_base, 0));
+    HCHK(hipMalloc(&s->d_needle, in1 < 16 ? 16 : in1));
+    HCHK(hipMalloc(&s->d_ridx, rows * sizeof(uint64_t)));
+    HCHK(hipMalloc(&s->d_rval, rows * rsz));
+    HCHK(hipMalloc(&s->d_peak, sizeof(caf_peak)));
+    const size_t spec1 = p->fused ? (size_t)2 * 16 * 256 * esz : p->chain ? p->L * esz : 0;
+    if (spec1) HCHK(hipMalloc(&s->d_spec, spec1 + 256));
+    if (p->chain && p->cR >= 4)
+        HCHK(hipMalloc(&s->d_slab, (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, esz, chain_nb_v(p->clogm, esz)) *
+                                       chain_slab_arrays_v(p->cR) * 16 * (((size_t)1 << p->clogm) / 16) * esz));
+    if (s->one_launch) {
+        HCHK(hipMalloc((void **)&s->d_sync, 512));
+        HCHK(hipMemsetAsync(s->d_sync, 0, 512, c->stream));
+        HCHK(hipStreamSynchronize(c->stream));
+    }
+#undef HCHK
+    s->stamp = ++c->host_clock;
+    c->host_slots.push_back(s);
+    *out = s;
+    return CAF_OK;
+}
+
+// device address for [p, p + bytes) if it lies inside memory of caf_host_alloc / caf_host_register, else NULL
+static char *host_range_dev(caf_ctx *c, const void *ptr, size_t bytes)
+{
+    if (c->host_ranges.empty()) return nullptr;
+    char *q = (char *)ptr;
+    auto it = c->host_ranges.upper_bound(q);
+    if (it == c->host_ranges.begin()) return nullptr;
+    --it;
+    if (q < it->first || q + bytes > it->first + it->second.bytes) return nullptr;
+    return it->second.dev + (q - it->first);
+}
+
+static void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#endif
+}
+
+// wait until a single-launch surface has published launch number `want` in its pinned sequence word; if the
+// poll runs out of patience, synchronise the stream and look again
+static int poll_seq(const unsigned long long *h_seq, size_t count, unsigned long long want, hipStream_t stream, const char *who)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long spins = 0;; ++spins) {
+        bool done = true;
+        for (size_t j = 0; j < count; ++j) done = done && __atomic_load_n(&h_seq[j], __ATOMIC_ACQUIRE) >= want;
+        if (done) return CAF_OK;
+        cpu_relax();
+        if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    for (size_t j = 0; j < count; ++j)
+        if (__atomic_load_n(&h_seq[j], __ATOMIC_ACQUIRE) < want)
+            return fail(CAF_ERR_HIP, "%s: the launch finished without publishing its results (sequence word %llu, expected %llu)",
+                        who, (unsigned long long)h_seq[j], want);
     return CAF_OK;
 }
 
@@ -1181,29 +1359,88 @@ static int surface_host_impl(caf_ctx *c, const T *needle, const T *hay, size_t n
     if (!freqs && nfreq) return fail(CAF_ERR_BAD_ARG, "caf_surface: freqs_hz is NULL");
     if (!is_pow2(n)) return fail(CAF_ERR_LENGTH, "caf_surface: n=%zu is not a power of two >= 1", n);
     HIPCHK(hipSetDevice(c->device));
-    caf_plan *p = nullptr;
-    int rc = get_cached_plan(c, n, freqs, nfreq, fs, dtype, &p);
+    HostSlot *sp = nullptr;
+    int rc = get_host_slot(c, n, freqs, nfreq, fs, dtype, &sp);
     if (rc) return rc;
-    const size_t L = 2 * n, in_bytes = n * sizeof(cpx<T>);
-    if ((rc = c->io_needle.ensure(in_bytes))) return rc;
-    if ((rc = c->io_hay.ensure(in_bytes))) return rc;
-    if ((rc = c->io_ridx.ensure((nfreq ? nfreq : 1) * sizeof(uint64_t)))) return rc;
-    if ((rc = c->io_rval.ensure((nfreq ? nfreq : 1) * sizeof(T)))) return rc;
-    if ((rc = c->io_peak.ensure(sizeof(caf_peak)))) return rc;
-    if (surface && nfreq && (rc = c->io_surface.ensure(nfreq * L * sizeof(T)))) return rc;
-    HIPCHK(hipMemcpyAsync(c->io_needle.p, needle, in_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->io_hay.p, hay, in_bytes, hipMemcpyHostToDevice, c->stream));
-    rc = caf_surface_dev(p, c->io_needle.p, c->io_hay.p, 1, surface && nfreq ? c->io_surface.p : nullptr,
-                         (uint64_t *)c->io_ridx.p, c->io_rval.p, (caf_peak *)c->io_peak.p);
-    if (rc) return rc;
-    if (surface && nfreq)
-        HIPCHK(hipMemcpyAsync(surface, c->io_surface.p, nfreq * L * sizeof(T), hipMemcpyDeviceToHost, c->stream));
-    if (row_idx && nfreq)
-        HIPCHK(hipMemcpyAsync(row_idx, c->io_ridx.p, nfreq * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    if (row_val && nfreq)
-        HIPCHK(hipMemcpyAsync(row_val, c->io_rval.p, nfreq * sizeof(T), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(peak, c->io_peak.p, sizeof(caf_peak), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HostSlot &s = *sp;
+    caf_plan *p = s.plan;
+    const size_t L = 2 * n, in1 = n * sizeof(cpx<T>), surf_bytes = nfreq * L * sizeof(T);
+    const bool want_surface = surface && nfreq;
+    // where the row kernel stores the surface: the caller's buffer itself, or a device slab + one D2H copy
+    void *surf_target = nullptr;
+    bool in_place = false;
+    if (want_surface) {
+        surf_target = host_range_dev(c, surface, surf_bytes);
+        in_place = surf_target != nullptr;
+        if (!in_place) {
+            if ((rc = c->io_surface.ensure(surf_bytes))) return rc;
+            surf_target = c->io_surface.p;
+        }
+    }
+    memcpy(s.h_base, needle, in1);
+    memcpy(s.h_base + s.o_hay, hay, in1);
+    const PeakStageOut ho{(caf_peak *)(s.m_base + s.o_peak), (uint64_t *)(s.m_base + s.o_ridx), (void *)(s.m_base + s.o_rval)};
+    unsigned *const h_status = (unsigned *)(s.h_base + s.o_status);
+    unsigned long long *const h_seq = (unsigned long long *)(s.h_base + s.o_seq);
+    if (s.one_launch) {
+        rc = surface_single_launch<T>(p, c->stream, s.m_base, s.d_needle, s.m_base + s.o_hay, s.d_spec, surf_target,
+                                      (uint64_t *)s.d_ridx, s.d_rval, (caf_peak *)s.d_peak, ho, s.d_sync,
+                                      (unsigned *)(s.m_base + s.o_status), (unsigned long long *)(s.m_base + s.o_seq), false);
+        if (rc) return rc;
+        ++s.launches;
+    } else {
+        hipStream_t on = c->stream;
+        p->spec_override = s.d_spec;
+        p->slab_override = s.d_slab;
+        p->stage_out = ho;
+        hipError_t e1 = hipSuccess;
+        if (p->fused && in1 % 16 == 0
+#ifdef CAF_MEASURE
+            && p->variant != 2
+#endif
+        ) {  // the spectrum kernel stages the needle in itself
+            p->stage_in_src = s.m_base;
+            p->stage_in_dst = s.d_needle;
+            p->stage_in_bytes = in1;
+        } else {
+            const size_t in16 = (in1 / 16 + 255) / 256;
+            k_stage_copy<<<(unsigned)(in16 < 1 ? 1 : in16 > 1024 ? 1024 : in16), 256, 0, on>>>(
+                CopyJobs{{s.m_base, nullptr, nullptr}, {s.d_needle, nullptr, nullptr}, {in1, 0, 0}});
+            e1 = hipGetLastError();
+        }
+        rc = caf_surface_dev(p, s.d_needle, s.m_base + s.o_hay, 1, surf_target, (uint64_t *)s.d_ridx, s.d_rval,
+                             (caf_peak *)s.d_peak);
+        p->spec_override = nullptr;
+        p->slab_override = nullptr;
+        p->stage_out = PeakStageOut{nullptr, nullptr, nullptr};
+        p->stage_in_src = nullptr;
+        p->stage_in_dst = nullptr;
+        p->stage_in_bytes = 0;
+        if (rc) return rc;
+        if (e1 != hipSuccess) return fail(CAF_ERR_HIP, "stage copy launch: %s", hipGetErrorString(e1));
+    }
+    if (want_surface && !in_place)
+        HIPCHK(hipMemcpyAsync(surface, c->io_surface.p, surf_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (s.one_launch && !want_surface) {
+        if ((rc = poll_seq(h_seq, 1, s.launches, c->stream, "caf_surface"))) return rc;
+    } else {
+        // (a surface written in place is complete at the END of the kernel: its stores are not system-scope ones)
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (s.one_launch && __atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < s.launches)
+            return fail(CAF_ERR_HIP, "caf_surface: the launch finished without publishing its results");
+    }
+    if (s.one_launch && __atomic_load_n(h_status, __ATOMIC_ACQUIRE)) {  // a role ran into its wait bound
+        HIPCHK(hipStreamSynchronize(c->stream));
+        __atomic_store_n(h_status, 0u, __ATOMIC_RELEASE);
+        HIPCHK(hipMemsetAsync(s.d_sync, 0, 512, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *h_seq = 0;
+        s.launches = 0;
+        return fail(CAF_ERR_HIP, "caf_surface: the surface launch ran into its wait bound; results discarded");
+    }
+    if (row_idx && nfreq) memcpy(row_idx, s.h_base + s.o_ridx, nfreq * sizeof(uint64_t));
+    if (row_val && nfreq) memcpy(row_val, s.h_base + s.o_rval, nfreq * sizeof(T));
+    memcpy(peak, s.h_base + s.o_peak, sizeof(caf_peak));
     return CAF_OK;
 }
 
@@ -1221,6 +1458,52 @@ extern "C" int caf_surface_c64(caf_ctx *c, const float *needle, const float *hay
     return surface_host_impl<float>(c, needle, hay, n, freqs, nfreq, fs, surface, row_idx, row_val, peak, CAF_C64);
 }
 
+// ---- caller memory the kernels may write in place ------------------------------------------------------
+extern "C" int caf_host_alloc(caf_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out || !bytes) return fail(CAF_ERR_BAD_ARG, "caf_host_alloc: NULL argument or zero size");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(c->device));
+    void *h = nullptr, *m = nullptr;
+    hipError_t e = pinned_alloc(&h, bytes);
+    if (e != hipSuccess) return fail(CAF_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    e = hipHostGetDevicePointer(&m, h, 0);
+    if (e != hipSuccess) { (void)hipHostFree(h); return fail(CAF_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+    c->host_ranges[(char *)h] = HostRange{bytes, (char *)m, true};
+    *out = h;
+    return CAF_OK;
+}
+
+extern "C" int caf_host_register(caf_ctx *c, void *ptr, size_t bytes)
+{
+    if (!c || !ptr || !bytes) return fail(CAF_ERR_BAD_ARG, "caf_host_register: NULL argument or zero size");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->host_ranges.count((char *)ptr)) return fail(CAF_ERR_STATE, "caf_host_register: %p is already registered", ptr);
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterMapped));
+    void *m = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&m, ptr, 0);
+    if (e != hipSuccess) { (void)hipHostUnregister(ptr); return fail(CAF_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+    c->host_ranges[(char *)ptr] = HostRange{bytes, (char *)m, false};
+    return CAF_OK;
+}
+
+static int host_range_drop(caf_ctx *c, void *ptr, bool owned, const char *who)
+{
+    if (!c) return fail(CAF_ERR_BAD_ARG, "%s: ctx is NULL", who);
+    if (!ptr) return CAF_OK;
+    auto it = c->host_ranges.find((char *)ptr);
+    if (it == c->host_ranges.end() || it->second.owned != owned)
+        return fail(CAF_ERR_BAD_ARG, "%s: %p did not come from this context's %s", who, ptr, owned ? "caf_host_alloc" : "caf_host_register");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->host_ranges.erase(it);
+    if (owned) HIPCHK(hipHostFree(ptr));
+    else HIPCHK(hipHostUnregister(ptr));
+    return CAF_OK;
+}
+extern "C" int caf_host_free(caf_ctx *c, void *ptr) { return host_range_drop(c, ptr, true, "caf_host_free"); }
+extern "C" int caf_host_unregister(caf_ctx *c, void *ptr) { return host_range_drop(c, ptr, false, "caf_host_unregister"); }
+
 // --------------------------------------------------------------- find_peak --
 extern "C" int caf_find_peak(caf_ctx *c, const double *freqs, const uint64_t *row_idx, const double *row_val,
                              size_t nfreq, caf_peak *peak)
@@ -1230,22 +1513,20 @@ extern "C" int caf_find_peak(caf_ctx *c, const double *freqs, const uint64_t *ro
     if (nfreq > 0x7fffffffu) return fail(CAF_ERR_BAD_ARG, "caf_find_peak: too many rows");
     HIPCHK(hipSetDevice(c->device));
     int rc;
-    const size_t m = nfreq ? nfreq : 1;
-    if ((rc = c->io_a.ensure(m * sizeof(double)))) return rc;
-    if ((rc = c->io_ridx.ensure(m * sizeof(uint64_t)))) return rc;
-    if ((rc = c->io_rval.ensure(m * sizeof(double)))) return rc;
-    if ((rc = c->io_peak.ensure(sizeof(caf_peak)))) return rc;
+    // pinned: [freqs | row_idx | row_val | caf_peak]; k_peak reads the rows and writes the record in place
+    const size_t m = nfreq ? nfreq : 1, col = (m * 8 + 255) & ~(size_t)255;
+    if ((rc = c->pin_a.ensure(3 * col + 256))) return rc;
+    char *h = (char *)c->pin_a.h, *d = (char *)c->pin_a.m;
     if (nfreq) {
-        HIPCHK(hipMemcpyAsync(c->io_a.p, freqs, nfreq * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->io_ridx.p, row_idx, nfreq * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->io_rval.p, row_val, nfreq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        memcpy(h, freqs, nfreq * sizeof(double));
+        memcpy(h + col, row_idx, nfreq * sizeof(uint64_t));
+        memcpy(h + 2 * col, row_val, nfreq * sizeof(double));
     }
-    k_peak<double><<<1, 256, 0, c->stream>>>((const double *)c->io_a.p, (const uint64_t *)c->io_ridx.p,
-                                             (const double *)c->io_rval.p, (int)nfreq, 0, (caf_peak *)c->io_peak.p,
-                                             PeakStageOut{nullptr, nullptr, nullptr});
+    k_peak<double><<<1, 256, 0, c->stream>>>((const double *)d, (const uint64_t *)(d + col), (const double *)(d + 2 * col),
+                                             (int)nfreq, 0, (caf_peak *)(d + 3 * col), PeakStageOut{nullptr, nullptr, nullptr});
     KCHK();
-    HIPCHK(hipMemcpyAsync(peak, c->io_peak.p, sizeof(caf_peak), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(peak, h + 3 * col, sizeof(caf_peak));
     return CAF_OK;
 }
 
@@ -1466,11 +1747,11 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
         }
         if (spec1) SCHK(hipMalloc(&s.d_spec, split ? batch * spec_stride : batch * spec1 + 256));
         if (slab1) SCHK(hipMalloc(&s.d_slab, (split ? batch : 1) * slab1));
-        SCHK(hipHostMalloc(&s.h_needle, in_bytes, hipHostMallocDefault));
-        SCHK(hipHostMalloc(&s.h_hay, in_bytes, hipHostMallocDefault));
-        SCHK(hipHostMalloc(&s.h_peak, batch * sizeof(caf_peak), hipHostMallocDefault));
-        SCHK(hipHostMalloc(&s.h_ridx, ridx_bytes, hipHostMallocDefault));
-        SCHK(hipHostMalloc(&s.h_rval, rval_bytes, hipHostMallocDefault));
+        SCHK(pinned_alloc(&s.h_needle, in_bytes));
+        SCHK(pinned_alloc(&s.h_hay, in_bytes));
+        SCHK(pinned_alloc(&s.h_peak, batch * sizeof(caf_peak)));
+        SCHK(pinned_alloc(&s.h_ridx, ridx_bytes));
+        SCHK(pinned_alloc(&s.h_rval, rval_bytes));
         SCHK(hipMalloc(&s.d_needle, in_bytes));
         SCHK(hipMalloc(&s.d_ridx, ridx_bytes));
         SCHK(hipMalloc(&s.d_rval, rval_bytes));
@@ -1479,9 +1760,9 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
         if (one_launch) {
             SCHK(hipMalloc((void **)&s.d_sync, batch * 512));
             SCHK(hipMemset(s.d_sync, 0, batch * 512));
-            SCHK(hipHostMalloc((void **)&s.h_status, 64, hipHostMallocDefault));
+            SCHK(pinned_alloc((void **)&s.h_status, 64));
             memset(s.h_status, 0, 64);
-            SCHK(hipHostMalloc((void **)&s.h_seq, batch * sizeof(unsigned long long), hipHostMallocDefault));
+            SCHK(pinned_alloc((void **)&s.h_seq, batch * sizeof(unsigned long long)));
             memset(s.h_seq, 0, batch * sizeof(unsigned long long));
         }
         memset(s.h_needle, 0, in_bytes);
@@ -1643,8 +1924,8 @@ extern "C" int caf_stream_submit(caf_stream *st, int slot)
     int rc = slot_ok(st, slot);
     if (rc) return rc;
     HIPCHK(hipSetDevice(st->plan->ctx->device));
-    ++st->slots[slot].submits;
     HIPCHK(hipGraphLaunch(st->slots[slot].exec, st->slots[slot].stream));
+    ++st->slots[slot].submits;  // counted only once the replay is really enqueued (caf_stream_wait polls for this number)
     return CAF_OK;
 }
 
@@ -1653,17 +1934,7 @@ extern "C" int caf_stream_submit(caf_stream *st, int slot)
 // stream's completion signal; the stream itself is only synchronised when the poll runs out of patience.
 static int slot_wait(StreamSlot &s, size_t batch)
 {
-    if (s.h_seq) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned long spins = 0;; ++spins) {
-            bool done = true;
-            for (size_t j = 0; j < batch; ++j)
-                done = done && __atomic_load_n(&s.h_seq[j], __ATOMIC_ACQUIRE) >= s.submits;
-            if (done) return CAF_OK;
-            __builtin_ia32_pause();
-            if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
-        }
-    }
+    if (s.h_seq) return poll_seq(s.h_seq, batch, s.submits, s.stream, "caf_stream_wait");
     HIPCHK(hipStreamSynchronize(s.stream));
     return CAF_OK;
 }
@@ -1675,8 +1946,8 @@ extern "C" int caf_stream_wait(caf_stream *st, int slot, caf_peak *peaks, uint64
     StreamSlot &s = st->slots[slot];
     HIPCHK(hipSetDevice(st->plan->ctx->device));
     if ((rc = slot_wait(s, st->batch))) return rc;
-    if (s.h_status && *(volatile unsigned *)s.h_status) {  // a single-launch surface gave up waiting for its own lower tickets
-        *(volatile unsigned *)s.h_status = 0u;
+    if (s.h_status && __atomic_load_n(s.h_status, __ATOMIC_ACQUIRE)) {  // a single-launch surface gave up waiting for its own lower tickets
+        __atomic_store_n(s.h_status, 0u, __ATOMIC_RELEASE);
         HIPCHK(hipStreamSynchronize(s.stream));
         HIPCHK(hipMemset(s.d_sync, 0, st->batch * 512));
         memset(s.h_seq, 0, st->batch * sizeof(unsigned long long));
@@ -1721,8 +1992,8 @@ extern "C" int caf_stream_run(caf_stream *st, const void *needles, const void *h
                 memset((char *)s.h_needle + k * in1, 0, (batch - k) * in1);
                 memset((char *)s.h_hay + k * in1, 0, (batch - k) * in1);
             }
-            ++s.submits;
             HIPCHK(hipGraphLaunch(s.exec, s.stream));
+            ++s.submits;
         }
     }
     return CAF_OK;

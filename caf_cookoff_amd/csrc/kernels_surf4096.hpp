@@ -248,6 +248,9 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_surf
         uint32_t *si = reinterpret_cast<uint32_t *>(scratch + 32);
         if (L.lane == 63) { sv[L.wave] = bv; si[L.wave] = bi; }
     }
+    // EVERY wave's surface stores are in memory before the row is counted: the last row publishes the launch
+    // (h_seq) on the strength of that count, and a host that polls h_seq may read the surface right away
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (L.tid == 0) {
         const T *sv = reinterpret_cast<const T *>(scratch);
@@ -266,7 +269,8 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_surf
             __hip_atomic_store(&S.h_ridx[r], (uint64_t)ri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&S.h_rval[r], rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        if (!(ok && okh)) *(volatile unsigned *)S.status = 1u;
+        // (system scope like the row words: the flag must not reach the host behind the sequence word)
+        if (!(ok && okh)) __hip_atomic_store(S.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this row's peak is in memory before it is counted
         sh[1] = __hip_atomic_fetch_add(&S.sync[96], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CAF_ABI_VERSION 1
+#define CAF_ABI_VERSION 2
 
 enum caf_status {
     CAF_OK = 0,
@@ -116,6 +116,26 @@ int caf_surface_c64(caf_ctx *ctx, const float *needle, const float *haystack,
                     size_t n, const double *freqs_hz, size_t nfreq, uint32_t fs,
                     float *surface, uint64_t *row_idx, float *row_val,
                     caf_peak *peak);
+
+/* How the host-pointer calls run: the context keeps the plans (tables, staging, device buffers) of the four most
+ * recently used (n, freq list, fs, dtype) combinations -- what Xcor::new / clone buy in the reference
+ * (xcor_rustfft.rs:29-46,82-93) -- so alternating between a few shapes costs no set-up.  Inputs are copied into
+ * pinned staging by the CPU and read from there by the kernels; row peaks and the caf_peak record are written
+ * to pinned memory by the kernels.  n = 4096 is one kernel launch per call whose completion is a polled pinned
+ * word (peaks only: ~45 us per call on MI355X).  A requested surface (26 MB at 400 x 8192 complex128) is
+ * stored by the row kernel straight into the caller's buffer while the other rows compute IF that buffer is
+ * memory of caf_host_alloc / caf_host_register below; any other (pageable) buffer costs one device-to-host
+ * copy after the kernel. */
+
+/* Host memory the kernels of this context may address directly.  caf_host_alloc returns pinned memory
+ * (free it with caf_host_free, or let caf_ctx_destroy do it); caf_host_register pins a range the caller owns
+ * (page-locking 26 MB costs ~1.2 ms the first time: do it once for a long-lived buffer, never per call) until
+ * caf_host_unregister / caf_ctx_destroy.  A Rust host keeps one such arena inside its CafHip backend and builds
+ * the Vec<CafSurfaceRow> rows (mod.rs:156-161) from it. */
+int caf_host_alloc(caf_ctx *ctx, size_t bytes, void **out);
+int caf_host_free(caf_ctx *ctx, void *ptr);
+int caf_host_register(caf_ctx *ctx, void *ptr, size_t bytes);
+int caf_host_unregister(caf_ctx *ctx, void *ptr);
 
 /* find_peak over caller-held rows (mod.rs:31-42), evaluated on the device with
  * the same kernel the fused path uses. */
