@@ -92,6 +92,11 @@ SYMBOLS = [
     ("caf_stream_submit", _int, [_vp, _int]),
     ("caf_stream_wait", _int, [_vp, _int, _pp, _up, _vp]),
     ("caf_stream_surface", _vp, [_vp, _int]),
+    ("caf_multi_stream_share", _int, [_sz, _int, _int, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    ("caf_multi_stream_create", _int, [ctypes.POINTER(_int), _int, _sz, _dp, _sz, _u32, _int, _int, ctypes.POINTER(_vp)]),
+    ("caf_multi_stream_devices", _int, [_vp]),
+    ("caf_multi_stream_run", _int, [_vp, _vp, _vp, _sz, _pp, _up, _vp]),
+    ("caf_multi_stream_destroy", _int, [_vp]),
 ]
 
 _libs: dict = {}

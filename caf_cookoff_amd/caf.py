@@ -98,6 +98,35 @@ class Engine:
         self._check(self.lib.caf_ctx_device_info(self._h, ctypes.byref(cu), buf, 128))
         return cu.value, buf.value.decode()
 
+    # -- host memory the kernels may write in place ---------------------------------
+    def host_empty(self, shape, dtype) -> np.ndarray:
+        """``caf_host_alloc``: an uninitialised numpy array in pinned host memory of this context.
+        Passed as ``out=`` to :meth:`surface_arrays` the row kernel stores the surface straight into it
+        (no device-to-host copy after the kernel).  The memory lives until the array (and every view of
+        it) is garbage-collected or the Engine is closed -- do not touch it after ``close()``."""
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        p = ctypes.c_void_p()
+        self._check(self.lib.caf_host_alloc(self._h, max(nbytes, 1), ctypes.byref(p)))
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
+        lib, eng_ref, addr = self.lib, weakref.ref(self), p.value
+
+        def _free():
+            e = eng_ref()
+            if e is not None and getattr(e, "_h", None):
+                lib.caf_host_free(e._h, ctypes.c_void_p(addr))
+        weakref.finalize(buf, _free)
+        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def host_register(self, arr: np.ndarray):
+        """``caf_host_register``: page-lock a caller-owned array (~1.2 ms per 26 MB: once per buffer,
+        not per call) so that surfaces can be written into it in place; undo with
+        :meth:`host_unregister` before the array is freed."""
+        self._check(self.lib.caf_host_register(self._h, ctypes.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def host_unregister(self, arr: np.ndarray):
+        self._check(self.lib.caf_host_unregister(self._h, ctypes.c_void_p(arr.ctypes.data)))
+
     # -- a1 -----------------------------------------------------------------------
     def apply_freq_shift(self, samples, freq_shift: float, fs: int) -> np.ndarray:
         """mod.rs:46-65."""
@@ -132,8 +161,10 @@ class Engine:
 
     # -- a5 -----------------------------------------------------------------------
     def surface_arrays(self, needle, haystack, freqs_hz, fs: int, want_surface: bool = True,
-                       dtype: str = "c128"):
-        """caf_surface as flat arrays: (surface[F,2n] | None, row_idx[F], row_val[F], CafPeak)."""
+                       dtype: str = "c128", out: Optional[np.ndarray] = None):
+        """caf_surface as flat arrays: (surface[F,2n] | None, row_idx[F], row_val[F], CafPeak).
+        ``out``: a C-contiguous [F, 2n] array of the dtype's real type to receive the surface (e.g. from
+        :meth:`host_empty`: written in place by the row kernel) instead of a fresh ``np.empty``."""
         if len(needle) != len(haystack):
             # caf_surface itself does not check; Xcor::run's assert trips (xcor_rustfft.rs:54-55)
             raise AssertionError("assertion failed: a.len() == self.n")
@@ -143,14 +174,14 @@ class Engine:
         peak = CafPeak()
         if dtype == "c64":
             nd, hs = _as_c64(needle), _as_c64(haystack)
-            surf = np.empty((F, 2 * n), dtype=np.float32) if want_surface else None
+            surf = self._surface_out(out, F, n, np.float32) if want_surface else None
             rval = np.zeros(F, dtype=np.float32)
             self._check(self.lib.caf_surface_c64(self._h, _fptr(nd.view(np.float32)), _fptr(hs.view(np.float32)), n,
                                            _dptr(fr), F, int(fs), _fptr(surf) if want_surface else None,
                                            _uptr(ridx), _fptr(rval), ctypes.byref(peak)))
         elif dtype == "c128":
             nd, hs = _as_c128(needle), _as_c128(haystack)
-            surf = np.empty((F, 2 * n), dtype=np.float64) if want_surface else None
+            surf = self._surface_out(out, F, n, np.float64) if want_surface else None
             rval = np.zeros(F, dtype=np.float64)
             self._check(self.lib.caf_surface_c128(self._h, _dptr(nd.view(np.float64)), _dptr(hs.view(np.float64)), n,
                                             _dptr(fr), F, int(fs), _dptr(surf) if want_surface else None,
@@ -158,6 +189,14 @@ class Engine:
         else:
             raise ValueError("dtype must be 'c128' or 'c64'")
         return surf, ridx, rval, peak
+
+    @staticmethod
+    def _surface_out(out, F, n, rdt):
+        if out is None:
+            return np.empty((F, 2 * n), dtype=rdt)
+        if out.shape != (F, 2 * n) or out.dtype != rdt or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous [{F}, {2 * n}] array of {np.dtype(rdt).name}")
+        return out
 
     def caf_surface(self, needle, haystack, freqs_hz, fs: int, want_surface: bool = True,
                     dtype: str = "c128") -> List[CafSurfaceRow]:
@@ -352,6 +391,63 @@ class Stream:
     def close(self):
         if getattr(self, "_h", None) and getattr(self.plan, "_h", None):
             self.plan.eng.lib.caf_stream_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def multi_stream_share(count: int, nworkers: int, worker: int) -> Tuple[int, int, int]:
+    """``caf_multi_stream_share``: (first, stride, items) of the pairs worker ``worker`` of ``nworkers``
+    handles out of ``count`` (round-robin).  Pure host arithmetic: works without a GPU."""
+    a, b, c = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    lib = _lib.load()
+    check(lib.caf_multi_stream_share(int(count), int(nworkers), int(worker), ctypes.byref(a), ctypes.byref(b),
+                                     ctypes.byref(c)), lib)
+    return a.value, b.value, c.value
+
+
+class MultiStream:
+    """``caf_multi_stream``: surface-parallel streaming over several devices (second
+    decomposition): one context + plan + stream per entry of ``devices`` (ids may repeat), whole surfaces
+    round-robin, results in input order, no collective."""
+
+    PEAK_DTYPE = Stream.PEAK_DTYPE
+
+    def __init__(self, devices: Sequence[int], n: int, freqs_hz, fs: int, dtype: str = "c128", nslots: int = 3):
+        self.lib = _lib.load()
+        self._h = None
+        fr = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        ids = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        h = ctypes.c_void_p()
+        check(self.lib.caf_multi_stream_create(ids, len(devices), int(n), _dptr(fr), len(fr), int(fs),
+                                               {"c128": CAF_C128, "c64": CAF_C64}[dtype], int(nslots), ctypes.byref(h)),
+              self.lib)
+        self._h = h
+        self.n, self.rows, self.ndev = int(n), len(fr), len(devices)
+        self._cdt = np.complex128 if dtype == "c128" else np.complex64
+        self._rdt = np.float64 if dtype == "c128" else np.float32
+
+    def run(self, needles, haystacks, want_rows: bool = False):
+        nd = np.ascontiguousarray(needles, dtype=self._cdt)
+        hs = np.ascontiguousarray(haystacks, dtype=self._cdt)
+        if nd.ndim != 2 or nd.shape != hs.shape or nd.shape[1] != self.n:
+            raise ValueError("needles / haystacks must be [count][n]")
+        count = nd.shape[0]
+        peaks = np.zeros(count, dtype=self.PEAK_DTYPE)
+        ridx = np.zeros((count, self.rows), dtype=np.uint64) if want_rows else None
+        rval = np.zeros((count, self.rows), dtype=self._rdt) if want_rows else None
+        check(self.lib.caf_multi_stream_run(self._h, ctypes.c_void_p(nd.ctypes.data), ctypes.c_void_p(hs.ctypes.data), count,
+                                            peaks.ctypes.data_as(ctypes.POINTER(CafPeak)), _uptr(ridx) if want_rows else None,
+                                            ctypes.c_void_p(rval.ctypes.data) if want_rows else None), self.lib)
+        return peaks, ridx, rval
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.caf_multi_stream_destroy(self._h)
         self._h = None
 
     def __del__(self):

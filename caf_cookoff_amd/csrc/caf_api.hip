@@ -1963,31 +1963,37 @@ extern "C" int caf_stream_wait(caf_stream *st, int slot, caf_peak *peaks, uint64
 
 // The whole streaming loop in native code (BASELINE configs[4]: `count` host-resident pairs, one after the
 // other): fill slot k's pinned buffers, replay its graph, collect slot k - nslots + 1 ... so that the
-// caller pays one call for the run instead of three per step.
-extern "C" int caf_stream_run(caf_stream *st, const void *needles, const void *haystacks, size_t count, caf_peak *peaks,
-                              uint64_t *row_idx, void *row_val)
+// caller pays one call for the run instead of three per step.  This worker handles the pairs
+// first, first + stride, ... (`items` of them) of the caller's arrays and writes their results at the same
+// positions: stride 1 is caf_stream_run, stride = number of devices is one worker of caf_multi_stream_run.
+static int stream_run_strided(caf_stream *st, const void *needles, const void *haystacks, size_t first0, size_t stride,
+                              size_t items, caf_peak *peaks, uint64_t *row_idx, void *row_val)
 {
-    if (!st) return fail(CAF_ERR_BAD_ARG, "stream is NULL");
-    if (count && (!needles || !haystacks || !peaks)) return fail(CAF_ERR_BAD_ARG, "caf_stream_run: NULL argument");
     const caf_plan *p = st->plan;
     const size_t batch = st->batch, nslots = st->slots.size(), rows = p->rows;
     const size_t in1 = p->n * elem_size(p->dtype), rsz = real_size(p->dtype);
-    const size_t nsteps = (count + batch - 1) / batch;
+    const size_t nsteps = (items + batch - 1) / batch;
     HIPCHK(hipSetDevice(p->ctx->device));
     for (size_t step = 0; step < nsteps + nslots; ++step) {
         StreamSlot &s = st->slots[step % nslots];
         if (step >= nslots && step - nslots < nsteps) {  // collect what this slot carried nslots steps ago
-            const size_t first = (step - nslots) * batch, k = count - first < batch ? count - first : batch;
+            const size_t j0 = (step - nslots) * batch, k = items - j0 < batch ? items - j0 : batch;
             int rc = caf_stream_wait(st, (int)(step % nslots), nullptr, nullptr, nullptr);
             if (rc) return rc;
-            memcpy(peaks + first, s.h_peak, k * sizeof(caf_peak));
-            if (row_idx && rows) memcpy(row_idx + first * rows, s.h_ridx, k * rows * sizeof(uint64_t));
-            if (row_val && rows) memcpy((char *)row_val + first * rows * rsz, s.h_rval, k * rows * rsz);
+            for (size_t j = 0; j < k; ++j) {
+                const size_t g = first0 + (j0 + j) * stride;
+                memcpy(peaks + g, (const caf_peak *)s.h_peak + j, sizeof(caf_peak));
+                if (row_idx && rows) memcpy(row_idx + g * rows, (const uint64_t *)s.h_ridx + j * rows, rows * sizeof(uint64_t));
+                if (row_val && rows) memcpy((char *)row_val + g * rows * rsz, (const char *)s.h_rval + j * rows * rsz, rows * rsz);
+            }
         }
         if (step < nsteps) {
-            const size_t first = step * batch, k = count - first < batch ? count - first : batch;
-            memcpy(s.h_needle, (const char *)needles + first * in1, k * in1);
-            memcpy(s.h_hay, (const char *)haystacks + first * in1, k * in1);
+            const size_t j0 = step * batch, k = items - j0 < batch ? items - j0 : batch;
+            for (size_t j = 0; j < k; ++j) {
+                const size_t g = first0 + (j0 + j) * stride;
+                memcpy((char *)s.h_needle + j * in1, (const char *)needles + g * in1, in1);
+                memcpy((char *)s.h_hay + j * in1, (const char *)haystacks + g * in1, in1);
+            }
             if (k < batch) {  // ragged tail: the unused surfaces of the slot run on zeros, their results are dropped
                 memset((char *)s.h_needle + k * in1, 0, (batch - k) * in1);
                 memset((char *)s.h_hay + k * in1, 0, (batch - k) * in1);
@@ -1996,6 +2002,105 @@ extern "C" int caf_stream_run(caf_stream *st, const void *needles, const void *h
             ++s.submits;
         }
     }
+    return CAF_OK;
+}
+
+extern "C" int caf_stream_run(caf_stream *st, const void *needles, const void *haystacks, size_t count, caf_peak *peaks,
+                              uint64_t *row_idx, void *row_val)
+{
+    if (!st) return fail(CAF_ERR_BAD_ARG, "stream is NULL");
+    if (count && (!needles || !haystacks || !peaks)) return fail(CAF_ERR_BAD_ARG, "caf_stream_run: NULL argument");
+    return stream_run_strided(st, needles, haystacks, 0, 1, count, peaks, row_idx, row_val);
+}
+
+// ------------------------------------------------------- surface-parallel multi-GPU --
+// The second multi-GPU decomposition (SURVEY.md section 8e "record both"): whole surfaces round-robin over the
+// devices -- the unit the reference's own pool hands out when many surfaces are wanted (one caf_surface call
+// per bench iteration, benches/caf_bench.rs:150-168; independent tasks, mod.rs:404-457).  One caf_ctx + caf_plan +
+// caf_stream per entry of `device_ids`, each driven by its own host thread for the length of a run; no
+// collective at all: a surface's (tau, f) is complete on the device that computed it.
+extern "C" int caf_multi_stream_share(size_t count, int nworkers, int worker, size_t *first, size_t *stride, size_t *items)
+{
+    if (nworkers <= 0 || worker < 0 || worker >= nworkers) return fail(CAF_ERR_BAD_ARG, "caf_multi_stream_share: worker %d of %d", worker, nworkers);
+    const size_t w = (size_t)worker, nw = (size_t)nworkers;
+    if (first) *first = w;
+    if (stride) *stride = nw;
+    if (items) *items = count > w ? (count - w + nw - 1) / nw : 0;  // pairs w, w + nw, w + 2 nw, ... < count
+    return CAF_OK;
+}
+
+struct MultiWorker {
+    int device = 0;
+    caf_ctx *ctx = nullptr;
+    caf_plan *plan = nullptr;
+    caf_stream *stream = nullptr;
+    int rc = CAF_OK;
+    std::string err;
+};
+struct caf_multi_stream {
+    std::vector<MultiWorker> workers;
+};
+
+extern "C" int caf_multi_stream_destroy(caf_multi_stream *ms)
+{
+    if (!ms) return CAF_OK;
+    for (auto &w : ms->workers) {
+        if (w.stream) caf_stream_destroy(w.stream);
+        if (w.plan) caf_plan_destroy(w.plan);
+        if (w.ctx) caf_ctx_destroy(w.ctx);
+    }
+    delete ms;
+    return CAF_OK;
+}
+
+extern "C" int caf_multi_stream_create(const int *device_ids, int ndev, size_t n, const double *freqs_hz, size_t nfreq,
+                                       uint32_t fs, int dtype, int nslots, caf_multi_stream **out)
+{
+    if (!out || !device_ids || ndev <= 0 || ndev > 64) return fail(CAF_ERR_BAD_ARG, "caf_multi_stream_create: bad device list");
+    *out = nullptr;
+    caf_multi_stream *ms = new (std::nothrow) caf_multi_stream;
+    if (!ms) return fail(CAF_ERR_NOMEM, "out of host memory");
+    ms->workers.resize(ndev);
+    for (int i = 0; i < ndev; ++i) {
+        MultiWorker &w = ms->workers[i];
+        w.device = device_ids[i];
+        int rc = caf_ctx_create(w.device, &w.ctx);
+        if (!rc) rc = caf_plan_create(w.ctx, n, freqs_hz, nfreq, fs, dtype, 0, nfreq, &w.plan);
+        if (!rc) rc = caf_stream_create(w.plan, 1, nslots, 0, &w.stream);
+        if (rc) {  // g_err of this thread holds the failing call's message
+            caf_multi_stream_destroy(ms);
+            return rc;
+        }
+    }
+    *out = ms;
+    return CAF_OK;
+}
+
+extern "C" int caf_multi_stream_devices(const caf_multi_stream *ms) { return ms ? (int)ms->workers.size() : 0; }
+
+extern "C" int caf_multi_stream_run(caf_multi_stream *ms, const void *needles, const void *haystacks, size_t count,
+                                    caf_peak *peaks, uint64_t *row_idx, void *row_val)
+{
+    if (!ms) return fail(CAF_ERR_BAD_ARG, "multi stream is NULL");
+    if (count && (!needles || !haystacks || !peaks)) return fail(CAF_ERR_BAD_ARG, "caf_multi_stream_run: NULL argument");
+    const int nw = (int)ms->workers.size();
+    std::vector<std::thread> threads;
+    for (int i = 0; i < nw; ++i) {
+        MultiWorker *w = &ms->workers[i];
+        w->rc = CAF_OK;
+        w->err.clear();
+        threads.emplace_back([=] {  // one host thread per device: the C ABI's contexts are single-threaded objects
+            size_t first = 0, stride = 1, items = 0;
+            caf_multi_stream_share(count, nw, i, &first, &stride, &items);
+            w->rc = stream_run_strided(w->stream, needles, haystacks, first, stride, items, peaks, row_idx, row_val);
+            if (w->rc) w->err = g_err;  // thread-local message of the worker thread
+        });
+    }
+    for (auto &t : threads) t.join();
+    for (int i = 0; i < nw; ++i)
+        if (ms->workers[i].rc)  // per-device error propagation: the first failing device, by position
+            return fail(ms->workers[i].rc, "caf_multi_stream_run: worker %d (device %d): %s", i, ms->workers[i].device,
+                        ms->workers[i].err.c_str());
     return CAF_OK;
 }
 

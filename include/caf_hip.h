@@ -255,6 +255,26 @@ int caf_stream_wait(caf_stream *st, int slot, caf_peak *peaks, uint64_t *row_idx
 /* Device address of the slot's surface slab ([batch][rows][2n]) or NULL. */
 void *caf_stream_surface(caf_stream *st, int slot);
 
+/* ---- surface-parallel multi-GPU streaming (second decomposition) ---------------
+ * Whole surfaces round-robin over devices: the unit of work the reference's callers hand out when many
+ * surfaces are wanted (one caf_surface call per iteration, benches/caf_bench.rs:150-168; independent pool tasks,
+ * mod.rs:404-457).  One caf_ctx + caf_plan + caf_stream (one surface per replay, `nslots` slots) per entry of
+ * device_ids -- an id may repeat: two contexts on one GPU -- each driven by its own host thread during a run.
+ * Pair k of the caller's arrays goes to worker k % ndev; peaks / row_idx / row_val come back in INPUT order.
+ * No collective: a surface's (tau, f) is complete on the device that computed it.  If workers fail, the call
+ * returns the status of the first failing one (by position) with its message.
+ * caf_multi_stream_share is the assignment rule by itself (no GPU needed): worker w of nworkers handles the
+ * `items` pairs first, first + stride, ... of `count`; ranks of a one-process-per-GPU job use it to pick their
+ * share of a common input set. */
+typedef struct caf_multi_stream caf_multi_stream;
+int caf_multi_stream_share(size_t count, int nworkers, int worker, size_t *first, size_t *stride, size_t *items);
+int caf_multi_stream_create(const int *device_ids, int ndev, size_t n, const double *freqs_hz, size_t nfreq,
+                            uint32_t fs, int dtype, int nslots, caf_multi_stream **out);
+int caf_multi_stream_devices(const caf_multi_stream *ms);
+int caf_multi_stream_run(caf_multi_stream *ms, const void *needles, const void *haystacks, size_t count,
+                         caf_peak *peaks, uint64_t *row_idx, void *row_val);
+int caf_multi_stream_destroy(caf_multi_stream *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,25 @@ inline caf_ctx *default_ctx()
     return h.c;
 }
 
+// Per-thread pinned arena (caf_host_alloc) the row kernel writes the surface into in place: a fresh
+// std::vector of 26 MB per call would cost more in page faults than the whole CAF.  Grows, never shrinks; freed
+// with the context.
+inline double *surface_arena(std::size_t values)
+{
+    static thread_local double *arena = nullptr;
+    static thread_local std::size_t cap = 0;
+    if (values > cap) {
+        if (arena) check(caf_host_free(default_ctx(), arena), "caf_host_free");
+        arena = nullptr;
+        cap = 0;
+        void *p = nullptr;
+        check(caf_host_alloc(default_ctx(), values * sizeof(double), &p), "caf_host_alloc");
+        arena = static_cast<double *>(p);
+        cap = values;
+    }
+    return arena;
+}
+
 struct CafHip {  // `pub struct CafHip {}  impl CafSurface for CafHip`
     // mod.rs:26-27.  Rows come back in freq-list order (like CafRustFFT / the rayon collect).
     static std::vector<CafSurfaceRow> caf_surface(const std::vector<Complex64> &needle,
@@ -57,16 +76,17 @@ struct CafHip {  // `pub struct CafHip {}  impl CafSurface for CafHip`
         if (needle.size() != haystack.size())  // Xcor::run's assert (xcor_rustfft.rs:54-55)
             throw std::runtime_error("assertion failed: a.len() == self.n");
         const std::size_t n = needle.size(), F = freqs_hz.size(), L = 2 * n;
-        std::vector<double> surf(F * L), val(F);
+        std::vector<double> val(F);
         std::vector<uint64_t> idx(F);
+        double *surf = (F > 0 && L > 0) ? surface_arena(F * L) : nullptr;
         caf_peak pk;
         check(caf_surface_c128(default_ctx(), reinterpret_cast<const double *>(needle.data()),
                                reinterpret_cast<const double *>(haystack.data()), n, freqs_hz.data(), F, fs,
-                               surf.data(), idx.data(), val.data(), &pk),
+                               surf, idx.data(), val.data(), &pk),
               "caf_surface_c128");
         std::vector<CafSurfaceRow> rows(F);
-        for (std::size_t r = 0; r < F; ++r)
-            rows[r] = CafSurfaceRow{freqs_hz[r], std::vector<double>(surf.begin() + r * L, surf.begin() + (r + 1) * L),
+        for (std::size_t r = 0; r < F; ++r)  // the row Vecs of mod.rs:156-161
+            rows[r] = CafSurfaceRow{freqs_hz[r], std::vector<double>(surf + r * L, surf + (r + 1) * L),
                                     static_cast<std::size_t>(idx[r]), val[r]};
         return rows;
     }

@@ -65,3 +65,26 @@ def test_xcor_interface_errors():
         caf.Xcor(12)  # not a power of two
     with pytest.raises(caf.CafError):
         caf.Xcor(0)
+
+
+@pytest.mark.parametrize("count,nworkers", [(0, 1), (1, 4), (10, 3), (37, 2), (1000, 8), (1001, 8), (5, 5), (64, 7)])
+def test_multi_stream_share_is_a_round_robin_partition(count, nworkers):
+    """caf_multi_stream_share (the ordering rule of the surface-parallel multi-GPU driver, pure host
+    arithmetic in the C-ABI library): pair k goes to worker k % nworkers, every pair exactly once, results at
+    the input positions; shares differ by at most one pair."""
+    import caf_cookoff_amd as caf
+    owner = np.full(count, -1)
+    sizes = []
+    for w in range(nworkers):
+        first, stride, items = caf.multi_stream_share(count, nworkers, w)
+        assert (first, stride) == (w, nworkers)
+        idx = first + stride * np.arange(items)
+        assert (idx < count).all() and (owner[idx] == -1).all()
+        owner[idx] = w
+        sizes.append(items)
+    assert (owner == np.arange(count) % nworkers).all()
+    assert sum(sizes) == count and max(sizes) - min(sizes) <= 1
+    with pytest.raises(caf.CafError):
+        caf.multi_stream_share(10, 0, 0)
+    with pytest.raises(caf.CafError):
+        caf.multi_stream_share(10, 2, 2)
