@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <new>
@@ -1321,6 +1322,30 @@ static char *host_range_dev(caf_ctx *c, const void *ptr, size_t bytes)
     return it->second.dev + (q - it->first);
 }
 
+// device -> host copy into caller memory.  hipMemcpyAsync rejects a destination that straddles the edge of a
+// registered range ("invalid argument"), so the copy is cut at the edges of this context's registered ranges:
+// every piece lies wholly inside one range or wholly in ordinary memory.
+static int d2h_copy(caf_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    char *d = (char *)dst;
+    const char *s = (const char *)src;
+    size_t done = 0;
+    while (done < bytes) {
+        size_t piece = bytes - done;
+        char *q = d + done;
+        auto it = c->host_ranges.upper_bound(q);  // first range starting beyond q
+        if (it != c->host_ranges.end() && (size_t)(it->first - q) < piece) piece = (size_t)(it->first - q);
+        if (it != c->host_ranges.begin()) {
+            auto in = std::prev(it);
+            char *end = in->first + in->second.bytes;
+            if (q < end && (size_t)(end - q) < piece) piece = (size_t)(end - q);
+        }
+        HIPCHK(hipMemcpyAsync(q, s + done, piece, hipMemcpyDeviceToHost, c->stream));
+        done += piece;
+    }
+    return CAF_OK;
+}
+
 static void cpu_relax()
 {
 #if defined(__x86_64__) || defined(__i386__)
@@ -1419,8 +1444,7 @@ static int surface_host_impl(caf_ctx *c, const T *needle, const T *hay, size_t n
         if (rc) return rc;
         if (e1 != hipSuccess) return fail(CAF_ERR_HIP, "stage copy launch: %s", hipGetErrorString(e1));
     }
-    if (want_surface && !in_place)
-        HIPCHK(hipMemcpyAsync(surface, c->io_surface.p, surf_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (want_surface && !in_place && (rc = d2h_copy(c, surface, c->io_surface.p, surf_bytes))) return rc;
     if (s.one_launch && !want_surface) {
         if ((rc = poll_seq(h_seq, 1, s.launches, c->stream, "caf_surface"))) return rc;
     } else {
