@@ -29,7 +29,15 @@ Rank 0 prints ONE JSON line (contract in the task statement) with
                  core counts stated);
   `extra`        (N = 1) the other BASELINE configs measured in the same process after the
                  headline: configs[2] complex64, configs[3] 4096 x 65536 complex64 (whole surface
-                 and the 512-row shard one of 8 GPUs gets), configs[4] streaming.
+                 and the 512-row shard one of 8 GPUs gets), configs[4] streaming -- each with its own
+                 `frac`, live `secondary` issue ceiling (`frac_of_ceiling`) and profiled `traffic`
+                 (`traffic_over_algorithmic`) -- and `host_api`: the literal drop-in calls
+                 (caf_surface_c128 with host pointers, peaks only / with the 26 MB surface,
+                 apply_freq_shift) timed from C by tests/cpp/host_api_time next to the PCIe floor;
+                 (N > 1) `configs3_c64_sharded`: every rank its row shard of ONE 4096 x 65536
+                 surface + the RCCL peak reduction, and `configs4_stream_surface_parallel`: whole
+                 surfaces round-robin over the ranks (the second multi-GPU decomposition), no
+                 collective on the data path.
 """
 from __future__ import annotations
 
@@ -64,8 +72,10 @@ def parse_args(argv=None):
     ap.add_argument("--nfreq", type=int, default=400)
     ap.add_argument("--n", type=int, default=N_SAMP, help="samples per input (4096 = configs[1]/[2]; "
                     "32768 with --nfreq 4096 --dtype c64 --batch 1 = configs[3])")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="cap on the whole CPU baseline leg (each figure "
+                    "is the median of >= 20 runs; ~3 s on a 16-core share)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the headline CPU figure: a 1-GPU box's "
+                    "CPU share is 16 cores; the all-usable-cores figure is reported beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[2]/[3]/[4] measurements (N = 1)")
@@ -132,7 +142,7 @@ def kernel_source_hash(kernel_name: str = "") -> str:
     return h.hexdigest()[:16]
 
 
-def profiled_traffic(kernel_name: str, nsurf: int, dtype: str):
+def profiled_traffic(kernel_name: str, nsurf: int, dtype: str, abytes=None):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command in separate passes, corrected as
     MI355X_MICROARCH.md prescribes; tools/profile_pack.py).  Collected offline, so it is only
@@ -145,7 +155,8 @@ def profiled_traffic(kernel_name: str, nsurf: int, dtype: str):
         except (OSError, ValueError):
             continue
         if t.get("kernel") and t["kernel"] in kernel_name and t.get("surfaces_per_launch") == nsurf and \
-                t.get("dtype") == ("f64" if dtype == "c128" else "f32"):
+                t.get("dtype") == ("f64" if dtype == "c128" else "f32") and \
+                (abytes is None or t.get("algorithmic_bytes_per_launch") in (None, abytes)):  # same rows per launch too
             if t.get("source_hash") == here:
                 best = (t["traffic_bytes_per_launch"], str(f.relative_to(ROOT)))
             else:
@@ -170,34 +181,55 @@ def host_cpu_info():
 
 
 def cpu_baseline(seconds: float, max_threads: int):
-    """C restatement of caf_rust (oracle/caf_oracle.c; 3 FFTs per row like
-    xcor_rustfft.rs:58-61, one task per row like CafRustFFTThreadpool) on the
-    reference's own chirp_0 bench input, timed on this host's cores."""
+    """C restatement of caf_rust (oracle/caf_oracle.c, one task per row like CafRustFFTThreadpool,
+    mod.rs:391-461) on the reference's own chirp_0 bench input, timed on this host's cores as SURVEY.md
+    section 8(d) prescribes: both flavours -- 3 FFTs per row exactly like xcor_rustfft.rs:58-61 (`value`),
+    and the hoisted 2-FFT variant (haystack spectrum once per surface) -- at 1 thread, at the box's CPU
+    share (<= --cpu-threads) and on every usable core (mod.rs:405 uses num_cpus::get()); every figure is
+    the MEDIAN of >= 20 timed runs (fewer only if the time cap is hit; the count is reported)."""
+    import statistics
     from oracle import caf_oracle as O
     info = host_cpu_info()
-    threads = max(1, min(info["nproc_usable"], max_threads))  # a 1-GPU box's CPU share is 16 cores
+    threads = max(1, min(info["nproc_usable"], max_threads))
     co = O.COracle()
     nd, hs = O.load_pair(O.default_data_dir(), "chirp_0_raw.c64", O.KATS[0][1])
     fr = O.bench_shifts()
     _, ridx, rval = co.caf_surface(nd, hs, fr, FS, want_surface=True, hoist=False, nthreads=threads)  # warm-up
     assert co.find_peak(fr, ridx, rval) == (69.0, 202)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        co.caf_surface(nd, hs, fr, FS, want_surface=True, hoist=False, nthreads=threads)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds and reps >= 3:
-            break
-    mt = el / reps
-    # single-thread figure (README.md:28 comparator) on a short sample
-    t1 = time.perf_counter()
-    co.caf_surface(nd, hs, fr, FS, want_surface=True, hoist=False, nthreads=1)
-    st = time.perf_counter() - t1
+    t_start = time.perf_counter()
+    runs_total = [0]
+
+    def median_ms(hoist, nthreads, share):
+        """median of >= 20 runs (at least 3 when this figure's share of the time cap runs out)"""
+        co.caf_surface(nd, hs, fr, FS, want_surface=True, hoist=hoist, nthreads=nthreads)
+        ts, t0 = [], time.perf_counter()
+        while len(ts) < 20 or (nthreads > 1 and len(ts) < 40 and time.perf_counter() - t0 < 0.15):
+            t1 = time.perf_counter()
+            co.caf_surface(nd, hs, fr, FS, want_surface=True, hoist=hoist, nthreads=nthreads)
+            ts.append(time.perf_counter() - t1)
+            if len(ts) >= 3 and time.perf_counter() - t0 > share:
+                break
+        runs_total[0] += len(ts)
+        return statistics.median(ts) * 1e3, len(ts)
+
+    figs = {}
+    plan = [("threads_%d" % threads, threads, 0.10)]
+    if info["nproc_usable"] > threads:
+        plan.append(("all_usable_cores_%d" % info["nproc_usable"], info["nproc_usable"], 0.10))
+    plan.append(("threads_1", 1, 0.30))
+    for name, nt, share in plan:
+        for flavour, hoist in (("3fft_per_row", False), ("2fft_hoisted", True)):
+            ms, runs = median_ms(hoist, nt, share * seconds)
+            figs.setdefault(name, {})[flavour] = {"ms_per_surface": ms, "surfaces_per_s": 1e3 / ms, "runs": runs}
+    head = figs["threads_%d" % threads]["3fft_per_row"]
+    el = time.perf_counter() - t_start
     return {
-        "value": 1.0 / mt, "unit": "surfaces/s", "cores": threads, "kind": "port",
-        "sample": f"{reps} x (400x8192 c128, chirp_0 pair, 3 FFTs/row, {threads} threads) in {el:.1f}s",
-        "ms_per_surface": mt * 1e3, "single_thread_ms_per_surface": st * 1e3,
+        "value": head["surfaces_per_s"], "unit": "surfaces/s", "cores": threads, "kind": "port",
+        "sample": f"median of {head['runs']} x (400x8192 c128, chirp_0 pair, 3 FFTs/row, {threads} threads); "
+                  f"{runs_total[0]} runs of all flavours in {el:.1f}s",
+        "ms_per_surface": head["ms_per_surface"],
+        "single_thread_ms_per_surface": figs["threads_1"]["3fft_per_row"]["ms_per_surface"],
+        "flavours": figs,
         "host_cpu": info["model"], "host_nproc": info["nproc_online"], "host_nproc_usable": info["nproc_usable"],
         "published_reference_ms": {"rust RustFFT 1 thread (R9-3900X)": 177, "rust RustFFT threadpool (R9-3900X)": 28},
     }
@@ -266,15 +298,20 @@ def roofline_entry(abytes, kern_ms):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
 
 
-def valu_ceiling(torch, dev, case, steps=10):
-    """FP64-VALU issue ceiling of the shipped row kernel, measured live: the measurement library's
-    math-only ablation (CAF_STORE_MODE=33: the product kernel's instruction stream with LDS traffic,
-    global loads and stores removed; wrong results, timing only) on the same batch and buffers."""
+def issue_ceiling(torch, dev, case, env, steps=10):
+    """Issue ceiling of a shipped row kernel, measured live: the measurement library's arithmetic-only
+    ablation of the SAME kernel (wrong results, timing only) on the same batch and buffers.
+      n = 4096 kernels   CAF_STORE_MODE=33: k_seq_rows / k_duo_rows with LDS traffic, barriers, global loads
+                         and stores removed -> what remains is the VALU instruction stream of the row
+      chain kernels      CAF_CHAIN_ABL=31 (configs[3]): no global memory, no workgroup barriers; the LDS
+                         exchanges of the chain stay (without them the values would have to live in registers
+                         and the kernel spills: DESIGN.md section 5)
+    -> kernel ms per launch, or None."""
     import caf_cookoff_amd as caf
     if not caf.MEASURE_LIB_PATH.exists():
         return None
-    old = os.environ.get("CAF_STORE_MODE")
-    os.environ["CAF_STORE_MODE"] = "33"
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         meng = caf.Engine(dev.index or 0, lib=caf.MEASURE_LIB_PATH)
         meng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -291,10 +328,47 @@ def valu_ceiling(torch, dev, case, steps=10):
         meng.close()
         return ms / max(1, launches)
     finally:
-        if old is None:
-            os.environ.pop("CAF_STORE_MODE", None)
-        else:
-            os.environ["CAF_STORE_MODE"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def secondary_entry(bound, ceil_ms, kern_ms, abytes, how):
+    return {"bound": bound, "ceiling_ms": ceil_ms, "frac_of_ceiling": ceil_ms / kern_ms,
+            "ceiling_frac_of_hbm": abytes / (ceil_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "how": how}
+
+
+def traffic_fields(kernel_name, nsurf, dtype, abytes):
+    """`traffic` (HBM bytes per launch from the committed PMC passes, only if their kernel-source hash equals
+    the running code's), where it came from, and its ratio to the algorithmic bytes."""
+    traffic, stale = profiled_traffic(kernel_name, nsurf, dtype, abytes)
+    return {"traffic": traffic[0] if traffic else None,
+            "traffic_over_algorithmic": traffic[0] / abytes if traffic else None,
+            "traffic_source": (traffic[1] + " (rocprofv3 PMC passes of this command, collected offline; "
+                               "kernel-source hash matches)") if traffic else
+                              (f"none: {stale} was measured on other kernel sources" if stale else None)}
+
+
+def host_api_times(reps=200):
+    """The literal drop-in calls timed from C (tests/cpp/host_api_time.cpp: caf_surface_c128 with host pointers,
+    peaks only / with the 26 MB surface into pageable, pinned and registered memory, caf_find_peak,
+    caf_apply_freq_shift_c128, caf_xcor_c128) next to the PCIe floor of this box.  Runs as a child process."""
+    exe = ROOT / "tests" / "cpp" / "host_api_time"
+    try:
+        if not exe.exists():
+            subprocess.run(["make", "-C", str(exe.parent), "host_api_time"], check=True, capture_output=True, timeout=300)
+        r = subprocess.run([str(exe), str(reps)], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout).strip()[-300:]}
+        out = json.loads(r.stdout)
+        out["how"] = ("tests/cpp/host_api_time (C, child process): medians; with_surface = caf_surface_c128 into a "
+                      "reused pageable buffer, in_place = into caf_host_alloc memory, pcie_floor = one pinned "
+                      "hipMemcpy D2H of the same 26 214 400 bytes; PCIe-inclusive, never `value`")
+        return out
+    except Exception as e:  # reported, never fatal for the bench line
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def stream_run(plan, nd, hs, lags, total, nslots, batch, split, three_kernels=False, native=True):
@@ -359,7 +433,8 @@ def stream_case(eng, torch, freqs, total=1000):
       batched4_2slots                 one batched chain of four surfaces per replay (for comparison)
       single_2slots_three_kernels     round-2a form {spectrum, rows, find_peak} as three nodes (for comparison)
       single_2slots_python_loop       submit / wait driven from Python, step by step (for comparison)
-    `value` = the best of the single-surface-granularity native forms."""
+    `value` = the FIXED form single_4slots (one surface per replay, four slots on probed-disjoint hardware
+    queues); the other forms are reported beside it, never selected from."""
     from caf_cookoff_amd.synth import make_batch
     plan = eng.plan(N_SAMP, freqs, FS)
     nd, hs, lags, _ = make_batch(64, N_SAMP, FS, seed0=5000)
@@ -374,11 +449,126 @@ def stream_case(eng, torch, freqs, total=1000):
         forms[name] = {"value": v, "us_per_surface": us, "tau_correct": okc}
     plan.close()
     abytes = algorithmic_bytes(1, 400, N_SAMP, "c128")
-    best = max(("single_2slots", "single_3slots", "single_4slots", "split4_2slots"), key=lambda k: forms[k]["value"])
+    best = "single_4slots"
     return {"workload": f"{total} back-to-back 400x8192 complex128 surfaces from host memory, hipGraph replay per slot, "
                         "stage-in of inputs and stage-out of peaks included, surfaces left on the device (BASELINE configs[4])",
             "value": forms[best]["value"], "unit": "surfaces/s", "form": best, "forms": forms,
             "algorithmic_bytes_per_surface": abytes, "frac": abytes * forms[best]["value"] / 1e9 / HBM_PEAK_GBS}
+
+
+def multi_stream_case(freqs, devices, total=1000):
+    """caf_multi_stream_* (surface-parallel decomposition inside ONE process): one context + plan + stream per
+    entry of `devices`, each on its own host thread, whole surfaces round-robin.  At N = 1 the bench runs it with
+    two contexts on the one GPU -- a functional leg (results checked), not a scaling claim."""
+    import numpy as np
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.synth import make_batch
+    nd, hs, lags, _ = make_batch(64, N_SAMP, FS, seed0=5000)
+    reps = (total + 63) // 64
+    a, b = np.tile(nd, (reps, 1))[:total], np.tile(hs, (reps, 1))[:total]
+    want = np.tile(np.asarray(lags), reps)[:total]
+    ms = caf.MultiStream(devices, N_SAMP, freqs, FS, nslots=3)
+    best = None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        peaks, _, _ = ms.run(a, b)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or rep == 1 else min(best, dt)
+    ms.close()
+    return {"value": total / best, "unit": "surfaces/s", "workers": len(devices), "slots_per_worker": 3,
+            "tau_correct": f"{int(np.sum(peaks['idx'] == want))}/{total}"}
+
+
+def multi_gpu_extras(args, eng, torch, dist, dev, rank, world, rehearse, freqs):
+    """N > 1 (every rank calls this; rank 0 keeps the result).
+    configs3_c64_sharded: BASELINE configs[3] as north_star words it -- ONE 4096 x 65536 complex64 surface, rank r
+      computes Doppler rows [r*4096/N, (r+1)*4096/N) and the global (tau, f) comes from the RCCL peak reduction;
+      value = surfaces/s of the whole job (K steps between barriers, max over ranks).
+    configs4_stream_surface_parallel: BASELINE configs[4] in the second decomposition -- 1000 host-resident pairs,
+      rank r streams pairs r, r + N, ... (caf_multi_stream_share) through its own caf_stream; no collective on the
+      data path; elapsed = all-reduce(MAX) over the ranks, value = 1000 / elapsed."""
+    import numpy as np
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.dist import reduce_global_peak
+    from caf_cookoff_amd.synth import make_batch
+    cdev = "cpu" if rehearse else dev
+
+    def all_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_sum(x):
+        t = torch.tensor([x], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+
+    def sync_all():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    out = {}
+    # ---- configs[3], Doppler-row shards + peak reduction
+    f3 = np.arange(4096) * 0.05 - 102.4
+    lo, hi = caf.shard_range(4096, rank, world)
+    c = Case(eng, torch, dev, 32768, f3, "c64", 1, lo, hi, seed0=3000)   # same seed on every rank: same pair
+
+    def step3():
+        c.launch()
+        pk = c.peak.cpu() if rehearse else c.peak
+        pki = pk.view(torch.int64)
+        return reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=args.peak_reduce, always_collective=True)
+
+    for _ in range(2):
+        g = step3()
+    sync_all()
+    K3 = 10
+    c.plan.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(K3):
+        g = step3()
+    sync_all()
+    el = all_max(time.perf_counter() - t0)
+    kms, nl = c.plan.timing_end()
+    gmax, grow, gidx = g
+    want_f = f3[np.argmin(np.abs(f3 - c.fos[0]))]
+    ok3 = int(gidx.cpu()[0]) == c.lags[0] and abs(float(f3[int(grow.cpu()[0])]) - want_f) <= 0.05 + 1e-9
+    ab = algorithmic_bytes(1, hi - lo, 32768, "c64")
+    out["configs3_c64_sharded"] = {
+        "workload": f"ONE 4096x65536 complex64 surface, Doppler rows sharded over {world} ranks "
+                    f"({hi - lo} rows on rank 0) + RCCL peak reduction ({args.peak_reduce}) (BASELINE configs[3])",
+        "value": K3 / el, "unit": "surfaces/s", "ms_per_surface": el / K3 * 1e3, "steps": K3,
+        "rank0_kernel_ms": kms / max(1, nl), "rank0_kernel": c.plan.kernel_name, "global_peak_correct": bool(ok3),
+        "rank0_algorithmic_bytes": ab, "rank0_frac": roofline_entry(ab, kms / max(1, nl))["frac"]}
+    c.close()
+    torch.cuda.empty_cache()
+    # ---- configs[4], whole surfaces round-robin over the ranks
+    total = 1000
+    nd, hs, lags, _ = make_batch(64, N_SAMP, FS, seed0=5000)
+    first, stride, items = caf.multi_stream_share(total, world, rank)
+    mine = (first + stride * np.arange(items)) % 64      # pair k of the run is pool entry k % 64
+    a, b, want = nd[mine], hs[mine], np.asarray(lags)[mine]
+    plan = eng.plan(N_SAMP, freqs, FS)
+    st = caf.Stream(plan, batch=1, nslots=4, want_surface=True)
+    st.run(a[:8], b[:8])     # warm the graphs
+    best = None
+    for rep in range(2):
+        sync_all()
+        t0 = time.perf_counter()
+        peaks, _, _ = st.run(a, b)
+        el4 = all_max(time.perf_counter() - t0)
+        best = el4 if best is None else min(best, el4)
+    okc = all_sum(int(np.sum(peaks["idx"] == want)))
+    st.close()
+    plan.close()
+    out["configs4_stream_surface_parallel"] = {
+        "workload": f"{total} back-to-back 400x8192 complex128 surfaces from host memory, whole surfaces round-robin over "
+                    f"{world} ranks ({items} on rank 0), one caf_stream (4 slots) per rank, no collective on the data path "
+                    "(BASELINE configs[4], surface-parallel decomposition)",
+        "value": total / best, "unit": "surfaces/s", "elapsed_ms_max_over_ranks": best * 1e3,
+        "tau_correct": f"{okc}/{total}"}
+    return out
 
 
 # -------------------------------------------------------------------------- plumbing only --
@@ -408,12 +598,32 @@ def plumbing_only(args):
     el = time.perf_counter() - t0
     assert torch.equal(grow, want_row) and torch.equal(gidx, torch.arange(nsurf) + 100) and bool((gmax == 9.0).all())
     n_seen = dist.get_world_size() if world > 1 else 1
+    # the N > 1 extras' control path on fabricated numbers: ONE surface whose rows are sharded (peak on global row
+    # 2500 of 4096, so exactly one rank owns it) and 1000 pairs shared out round-robin (counts summed over ranks)
+    import caf_cookoff_amd as caf
+    lo3, hi3 = shard_range(4096, rank, world)
+    own = lo3 <= 2500 < hi3
+    v3 = torch.tensor([7.0 if own else 0.5], dtype=torch.float64)
+    r3 = torch.tensor([2500 if own else lo3], dtype=torch.int64)
+    i3 = torch.tensor([123 if own else 9], dtype=torch.int64)
+    g3 = reduce_global_peak(v3, r3, i3, method=args.peak_reduce)
+    first, stride, items = caf.multi_stream_share(1000, world, rank)
+    cnt = torch.tensor([items], dtype=torch.int64)
+    tmax = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    extra = {"configs3_c64_sharded": {"plumbing": True, "global_peak_correct": (float(g3[0][0]), int(g3[1][0]), int(g3[2][0])) == (7.0, 2500, 123),
+                                      "rows_rank0": hi3 - lo3 if rank == 0 else None},
+             "configs4_stream_surface_parallel": {"plumbing": True, "pairs_total": int(cnt.item()), "pairs_rank0": items,
+                                                  "elapsed_ms_max_over_ranks": float(tmax.item()) * 1e3}}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"plumbing_only": True, "n_gpus": n_seen, "steps": args.steps, "value": None,
-                          "ms_per_step": el / max(1, args.steps) * 1e3, "peak_reduce": args.peak_reduce}), flush=True)
+                          "ms_per_step": el / max(1, args.steps) * 1e3, "peak_reduce": args.peak_reduce,
+                          "extra": extra}), flush=True)
     return 0
 
 
@@ -570,11 +780,10 @@ def main():
         kern_ms = kern_ms_total / max(1, launches)
         abytes = algorithmic_bytes(nsurf, rows, n_samp, args.dtype)
         roof = roofline_entry(abytes, kern_ms)
-        traffic, stale = profiled_traffic(plan.kernel_name, nsurf, args.dtype) if world == 1 else (None, None)
-        roof.update({"traffic": traffic[0] if traffic else None,
-                     "traffic_source": (traffic[1] + " (rocprofv3 PMC passes of this command, collected offline; "
-                                        "kernel-source hash matches)") if traffic else
-                                       (f"none: {stale} was measured on other kernel sources" if stale else None),
+        tf = traffic_fields(plan.kernel_name, nsurf, args.dtype, abytes) if world == 1 else \
+            {"traffic": None, "traffic_over_algorithmic": None, "traffic_source": None}
+        roof.update(tf)
+        roof.update({
                      "kernel": plan.kernel_name, "kernel_ms": kern_ms, "launches_timed": launches,
                      "algorithmic_bytes_per_launch": abytes,
                      "frac_of_achievable_6.29TBs": roof["achieved"] / HBM_ACHIEVABLE_GBS,
@@ -595,18 +804,18 @@ def main():
                        "devices_visible_per_rank": ndev, "kernel_source_hash": kernel_source_hash(plan.kernel_name)},
             "roofline": roof,
         }
-    # ---- live FP64-VALU ceiling of the shipped instruction stream (headline shape only) ----
-    if rank == 0 and world == 1 and args.dtype == "c128" and n_samp == N_SAMP and not args.no_ceiling:
+    # ---- live VALU issue ceiling of the shipped instruction stream (n = 4096 shapes) ----
+    if rank == 0 and world == 1 and n_samp == N_SAMP and not args.no_ceiling:
         try:
-            ceil_ms = valu_ceiling(torch, dev, case)
+            ceil_ms = issue_ceiling(torch, dev, case, {"CAF_STORE_MODE": "33"})
         except Exception as e:  # measurement aid only: never fail the bench line for it
             ceil_ms = None
             print(f"bench.py: VALU ceiling not measured: {e}", file=sys.stderr)
         if ceil_ms:
-            res["roofline"]["secondary"] = {
-                "bound": "valu_f64", "ceiling_ms": ceil_ms, "frac_of_ceiling": ceil_ms / res["roofline"]["kernel_ms"],
-                "ceiling_frac_of_hbm": res["roofline"]["algorithmic_bytes_per_launch"] / (ceil_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "how": "math-only ablation of the product kernel (libcaf_hip_measure.so, CAF_STORE_MODE=33), same batch"}
+            res["roofline"]["secondary"] = secondary_entry(
+                "valu_f64" if args.dtype == "c128" else "valu_packed_f32", ceil_ms, res["roofline"]["kernel_ms"],
+                res["roofline"]["algorithmic_bytes_per_launch"],
+                "math-only ablation of the product kernel (libcaf_hip_measure.so, CAF_STORE_MODE=33), same batch")
     case.close()
 
     # ---- the other BASELINE configs, same process, after the headline (N = 1 only) ------
@@ -614,7 +823,7 @@ def main():
         extra = {}
         torch.cuda.empty_cache()
 
-        def plan_case(name, n, freqs_x, dtype, batch, lo_x, hi_x, steps, warmup, cfg):
+        def plan_case(name, n, freqs_x, dtype, batch, lo_x, hi_x, steps, warmup, cfg, ceiling=None):
             c = Case(eng, torch, dev, n, freqs_x, dtype, batch, lo_x, hi_x, seed0=3000)
             try:
                 sec, kms, nl = c.timed(steps, warmup)
@@ -628,23 +837,50 @@ def main():
                                else "row-shards/s", "ms_per_step": sec * 1e3, "steps": steps,
                                "kernel": c.plan.kernel_name, "kernel_path": c.plan.path, "kernel_ms": kms,
                                "algorithmic_bytes": ab, "achieved_GBs": e["achieved"], "frac": e["frac"]}
+                extra[name].update(traffic_fields(c.plan.kernel_name, batch, dtype, ab))
+                if ceiling and not args.no_ceiling:
+                    bound, env, how = ceiling
+                    try:
+                        cms = issue_ceiling(torch, dev, c, env, steps=min(10, steps))
+                        if cms:
+                            extra[name]["secondary"] = secondary_entry(bound, cms, kms, ab, how)
+                    except Exception as ex:
+                        extra[name]["secondary_error"] = f"{type(ex).__name__}: {ex}"
             finally:
                 c.close()
                 torch.cuda.empty_cache()
 
         try:
             plan_case("configs2_c64", N_SAMP, freqs, "c64", args.batch, 0, 400, max(5, min(K, 30)), 3,
-                      "400x8192 complex64 filterbank CAF (BASELINE configs[2]), batch %d" % args.batch)
+                      "400x8192 complex64 filterbank CAF (BASELINE configs[2]), batch %d" % args.batch,
+                      ceiling=("valu_packed_f32", {"CAF_STORE_MODE": "33"},
+                               "math-only ablation of k_duo_rows<float> (libcaf_hip_measure.so, CAF_STORE_MODE=33: the "
+                               "product kernel body over a null memory policy), same batch"))
             f3 = np.arange(4096) * 0.05 - 102.4   # 0.05 Hz grid
             plan_case("configs3_c64_full", 32768, f3, "c64", 1, 0, 4096, 5, 2,
-                      "4096x65536 complex64 filterbank CAF, all rows on ONE GPU (BASELINE configs[3] shape)")
+                      "4096x65536 complex64 filterbank CAF, all rows on ONE GPU (BASELINE configs[3] shape)",
+                      ceiling=("valu_plus_lds_exchanges", {"CAF_CHAIN_ABL": "31"},
+                               "k_chain_rows<float, 14, 4> without global memory and workgroup barriers "
+                               "(libcaf_hip_measure.so, CAF_CHAIN_ABL=31), same rows"))
             lo3, hi3 = caf.shard_range(4096, 3, 8)
             plan_case("configs3_c64_shard", 32768, f3, "c64", 1, lo3, hi3, 10, 2,
                       "rows [1536,2048) of 4096x65536 complex64: the shard rank 3 of 8 GPUs computes (BASELINE configs[3])")
             extra["configs4_stream"] = stream_case(eng, torch, freqs, total=1000)
+            extra["configs4_stream"]["multi_ctx2_same_gpu"] = multi_stream_case(freqs, [local_rank, local_rank], total=1000)
         except Exception as e:
             extra["error"] = f"{type(e).__name__}: {e}"
+        extra["host_api"] = host_api_times()
         res["extra"] = extra
+
+    # ---- N > 1: the two multi-GPU decompositions of the other configs, all ranks take part ------
+    if coll and not args.no_extra and F == 400 and n_samp == N_SAMP and args.dtype == "c128":
+        torch.cuda.empty_cache()
+        try:
+            ex = multi_gpu_extras(args, eng, torch, dist, dev, rank, world, rehearse, freqs)
+        except Exception as e:
+            ex = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            res["extra"] = ex
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

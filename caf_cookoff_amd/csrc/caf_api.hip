@@ -32,6 +32,7 @@
 #include "kernels_r8_4096.hpp"
 #include "kernels_big65536.hpp"  // four-step tiled n = 32768 path of round 1 (CAF_CHAIN=0), superseded by the chain path
 #include "kernels_q65536.hpp"
+#include "kernels_ablate.hpp"     // arithmetic-only memory policies (issue ceilings; wrong results)
 #endif
 
 using namespace caf;
@@ -689,7 +690,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
     if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
     if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0, 15>" : "caf::k_seq_rows<float, 0, 0, 15>";
     if (p->variant == 2) return f64 ? "caf::k_r8_rows<double, 0>" : "caf::k_r8_rows<float, 0>";
-    if (p->variant == 3) return f64 ? "caf::k_duo_rows<double, 0>" : "caf::k_duo_rows<float, 0>";
+    if (p->variant == 3) return f64 ? "caf::k_duo_rows<double, 0, caf::DuoIo<double> >" : "caf::k_duo_rows<float, 0, caf::DuoIo<float> >";
     return f64 ? "caf::k_fused_rows<double, false>" : "caf::k_fused_rows<float, false>";
 }
 
@@ -829,6 +830,8 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
             k_fused_rows<T, false><<<gf, F_THREADS, 0, c->stream>>>(a);
     } else if (p->variant == 3 && store_mode == 3) {
         k_duo_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
+    } else if (p->variant == 3 && store_mode == 33) {  // VALU only: the product body over the null memory policy
+        k_duo_rows<T, 0, DuoIoNull<T>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
     } else if (p->variant == 0 && p->dbg) {
         k_seq_rows<T, 0, 8, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
     } else if (p->variant == 0 && store_mode != 0) {

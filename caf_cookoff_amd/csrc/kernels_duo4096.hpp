@@ -67,18 +67,32 @@ struct DuoIo {
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twB[16 * k]);
     }
+    // every other access to memory the row makes goes through these hooks too, so that the measurement
+    // library can instantiate the SAME kernel body with a policy that keeps everything in registers
+    // (kernels_ablate.hpp, DuoIoNull: the packed-f32 / FP64 issue ceiling bench.py reports); the product
+    // library only ever instantiates this policy
+    __device__ __forceinline__ void sink_A(int k, cpx<T> x) const { Lc[L.pA + k * F_BLK] = x; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ void fence() const { wave_lds_fence(); }
+    __device__ __forceinline__ void samples(cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t rs) const { load_samples(a, rs, L); }
+    __device__ __forceinline__ cpx<T> sample(const __amdgpu_buffer_rsrc_t rs, int i) const
+    {
+        return bload(rs, (unsigned)(L.t * sizeof(cpx<T>)), (unsigned)(256 * i * sizeof(cpx<T>)), (cpx<T> *)nullptr);
+    }
+    __device__ __forceinline__ void spectrum(cpx<T> (&h)[16], const __amdgpu_buffer_rsrc_t rs_spec, int chain) const
+    {
+        const unsigned voff = (unsigned)((chain * 4096 + L.t) * sizeof(cpx<T>));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff, (unsigned)(256 * k * sizeof(cpx<T>)), (cpx<T> *)nullptr);
+    }
+    template <typename V>
+    __device__ __forceinline__ void store(const __amdgpu_buffer_rsrc_t rs, unsigned byte_off, V d) const
+    {
+        store_vec_aux<CAF_AUX_SC1>(rs, byte_off, d);
+    }
 };
 
-template <typename T>
-__device__ __forceinline__ void load_spec(cpx<T> (&h)[16], const __amdgpu_buffer_rsrc_t rs_spec, int chain, const SeqLane &L)
-{
-    using C = cpx<T>;
-    const unsigned voff = (unsigned)((chain * 4096 + L.t) * sizeof(C));
-#pragma unroll
-    for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
-}
-
-template <typename T, int STORE = 0>
+template <typename T, int STORE = 0, typename IO = DuoIo<T>>
 __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_duo_rows(const FusedArgs<T> A,
                                                                              const cpx<T> *__restrict__ phasor)
 {
@@ -97,7 +111,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_duo_rows
     tw.w8 = A.tab.tw4096[L.t * 8];
     tw.w12 = A.tab.tw4096[L.t * 12];
     twb[L.tid] = A.tab.tw4096[16 * (L.tid & 15) * (L.tid >> 4)];
-    const DuoIo<T> io{Lc, twb + L.lo4, L};
+    const IO io{Lc, twb + L.lo4, L};
     const C th = A.tab.th[L.t];  // T^t = e^{2*pi*i*t/8192}
     const C cfac = conj(th);     // odd chain input rotation e^{-2*pi*i*t/8192}
     const int mpair = L.t & ~1;
@@ -108,8 +122,8 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_duo_rows
     C a[16];
     {
         const int gc = (int)blockIdx.x < A.total ? (int)blockIdx.x : A.total - 1;
-        load_samples(a, __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0,
-                                                          F_N * (int)sizeof(C), 0x00020000), L);
+        io.samples(a, __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0,
+                                                        F_N * (int)sizeof(C), 0x00020000));
     }
     volatile int *const next_row = reinterpret_cast<volatile int *>(scratch + 112);
     C pb;
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_duo_rows
         for (int q = 0; q < 16; ++q) e[q] = cmul_conj(a[q], ph[32 + q]);
         {
             const TwFold<T> fe(tw, conj(pb));
-            dft16_sink(e, [&](int k, C x) { Lc[L.pA + k * F_BLK] = twA_k(x, k, tw, fe); });  // E.W_A
+            dft16_sink(e, [&](int k, C x) { io.sink_A(k, twA_k(x, k, tw, fe)); });  // E.W_A
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) o[q] = cmul_conj(a[q], ph[48 + q]);
@@ -142,64 +156,64 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_duo_rows
 #pragma unroll
             for (int k = 0; k < 16; ++k) o[k] = twA_k(o[k], k, tw, fo);
         }
-        __syncthreads();  // B1
+        io.sync();  // B1
         io.read_B(e);
         // the ticket was stored before B1: visible to every wave by now
         const int gn = __builtin_amdgcn_readfirstlane(*next_row);
         const int gc = gn < A.total ? gn : A.total - 1;  // clamped: a[] is always redefined
-        __syncthreads();  // B2: every wave holds its E data, the area is free
+        io.sync();  // B2: every wave holds its E data, the area is free
         io.write_A(o);    // O.W_A
         // ---- E.S2 under O.W_A ----
         dft16(e);
         io.mul_twB(e);
-        __syncthreads();  // B3
+        io.sync();  // B3
         io.read_B(o);
         io.write_B(e);
-        wave_lds_fence();
+        io.fence();
         io.read_C(e);
         // ---- O.S2 under E's wave-local exchange ----
         dft16(o);
         io.mul_twB(o);
-        wave_lds_fence();  // E.R_C (other lanes' pattern-B slots) before they are overwritten
+        io.fence();  // E.R_C (other lanes' pattern-B slots) before they are overwritten
         io.write_B(o);
-        wave_lds_fence();
+        io.fence();
         io.read_C(o);
         // ---- E.S3: last forward butterfly, spectrum product (xcor_rustfft.rs:64-73), first inverse one
-        load_spec(h, rs_spec, 0, L);  // (earlier costs 33 f64 spills; the butterfly below covers the L2 latency)
+        io.spectrum(h, rs_spec, 0);  // (earlier costs 33 f64 spills; the butterfly below covers the L2 latency)
         dft16(e);
 #pragma unroll
         for (int k = 0; k < 16; ++k) e[k] = cmul(e[k], h[k]);
         dft16(e);
-        load_spec(h, rs_spec, 1, L);
-        wave_lds_fence();
+        io.spectrum(h, rs_spec, 1);
+        io.fence();
         io.write_C(e);
-        wave_lds_fence();
+        io.fence();
         io.read_B(e);
         // ---- O.S3 ----
         dft16(o);
 #pragma unroll
         for (int k = 0; k < 16; ++k) o[k] = cmul(o[k], h[k]);
         dft16(o);
-        wave_lds_fence();
+        io.fence();
         io.write_C(o);
-        wave_lds_fence();
+        io.fence();
         io.read_B(o);
         // ---- E.S4 ----
         io.mul_twB(e);
         dft16(e);
-        wave_lds_fence();
+        io.fence();
         io.write_B(e);
         // ---- O.S4 under E.W_B ----
         io.mul_twB(o);
         dft16(o);
-        __syncthreads();  // B4
+        io.sync();  // B4
         io.read_A(e);
-        __syncthreads();  // B5: every wave holds its E data
+        io.sync();  // B5: every wave holds its E data
         io.write_B(o);
         // ---- E.S5 under O.W_B ----
         apply_twA(e, tw);
         dft16(e);
-        __syncthreads();  // B6
+        io.sync();  // B6
         io.read_A(o);
         {
             const TwFold<T> fpost(tw, th);  // T^t of the last radix-2 stage folded into the twiddles
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_duo_rows
             bv_lo = vmax(bv_lo, mlo[i]);
             bi_hi = mhi[i] > bv_hi ? i : bi_hi;
             bv_hi = vmax(bv_hi, mhi[i]);
-            a[i] = bload(rs_sig_next, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * i * sizeof(C)), (C *)nullptr);
+            a[i] = io.sample(rs_sig_next, i);
         }
         {   // phasor base of the next row
             const C *phn = phasor + (size_t)(gc % A.rows) * 64;
@@ -240,8 +254,8 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_duo_rows
             pair_xor1(mhi[2 * j], mhi[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dhi);
             const int m = mpair + 256 * (2 * j + (odd ? 1 : 0));
             if constexpr (STORE != 3) {
-                store_vec_aux<CAF_AUX_SC1>(rs, (unsigned)(m * sizeof(T)), dlo);
-                store_vec_aux<CAF_AUX_SC1>(rs, (unsigned)((m + F_N) * sizeof(T)), dhi);
+                io.store(rs, (unsigned)(m * sizeof(T)), dlo);
+                io.store(rs, (unsigned)((m + F_N) * sizeof(T)), dhi);
             } else {
                 asm volatile("" ::"v"(dlo), "v"(dhi));
             }

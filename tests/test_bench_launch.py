@@ -28,6 +28,12 @@ def test_self_launch_two_ranks_plumbing_only():
         lines = _json_lines(r.stdout)
         assert len(lines) == 1, r.stdout                     # exactly ONE line, from rank 0
         assert lines[0]["n_gpus"] == 2 and lines[0]["plumbing_only"] and lines[0]["peak_reduce"] == method
+        # the N > 1 line carries BOTH multi-GPU decompositions of the other configs: configs[3] as Doppler-row
+        # shards of one surface + peak reduction, configs[4] as whole surfaces round-robin over the ranks
+        ex = lines[0]["extra"]
+        assert ex["configs3_c64_sharded"]["global_peak_correct"] and ex["configs3_c64_sharded"]["rows_rank0"] == 2048
+        sp = ex["configs4_stream_surface_parallel"]
+        assert sp["pairs_total"] == 1000 and sp["pairs_rank0"] == 500 and abs(sp["elapsed_ms_max_over_ranks"] - 2.0) < 1e-9
 
 
 def test_single_rank_plumbing_needs_no_launcher():
@@ -58,6 +64,6 @@ def test_algorithmic_bytes_match_survey_8d():
     assert big == 2 * 262_144 + 4096 * 65536 * 4 + 4096 * 12
     assert len(bench.kernel_source_hash()) == 16
     # per-kernel: the streaming header is not part of the batched row kernels' sources
-    h = {k: bench.kernel_source_hash(k) for k in ("caf::k_seq_rows<double, 0, 0, 15>", "caf::k_duo_rows<float, 0>",
+    h = {k: bench.kernel_source_hash(k) for k in ("caf::k_seq_rows<double, 0, 0, 15>", "caf::k_duo_rows<float, 0, caf::DuoIo<float> >",
                                                    "caf::k_chain_rows<float, 14, 4, 1, 0>", "")}
     assert len(set(h.values())) == 4
