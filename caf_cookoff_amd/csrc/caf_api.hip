@@ -23,6 +23,7 @@
 #include "kernels_surf4096.hpp"
 #include "kernels_duo4096.hpp"
 #include "kernels_chain.hpp"
+#include "kernels_small.hpp"
 #include "kernels_generic.hpp"
 // Measurement build (-DCAF_MEASURE -> libcaf_hip_measure.so, used by tools/ and the variant
 // tests only): rejected kernel variants, ablation instantiations that produce WRONG results and
@@ -152,6 +153,8 @@ struct caf_ctx {
     void *qoutw[2] = {nullptr, nullptr};    // 16x4096 path: W_L^(k1 t)
     // generic FFT twiddles per (L, dtype)
     std::map<std::pair<size_t, int>, void *> tw_cache;
+    // small-path tables per (L, dtype): e^{2 pi i m / L}, m < L
+    std::map<std::pair<size_t, int>, void *> small_tabs;
     // chain-path tables per (LOGM, R, dtype): {twM, th}
     std::map<std::tuple<int, int, int>, std::pair<void *, void *>> chain_tabs;
     // host-pointer entry points: cached plans + their staging slots (LRU), shared work buffers
@@ -177,6 +180,8 @@ struct caf_plan {
     size_t nfreq_total = 0, row_begin = 0, rows = 0;
     bool fused = false;
     bool big = false;           // n == 32768 complex128: four-step tiled path
+    bool small = false;         // n <= 512: lane-group rows (kernels_small.hpp)
+    void *s_twL = nullptr;      //   ... its W_L table (borrowed from the ctx cache)
     bool chain = false;         // LDS-resident chain path (kernels_chain.hpp): R chains of 2^logm points
     int clogm = 0, cR = 0;
     void *c_twM = nullptr, *c_th = nullptr;  // borrowed from the ctx cache
@@ -317,6 +322,7 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
     for (auto st_ : c->slot_pool)
         if (st_ != c->own_stream) (void)hipStreamDestroy(st_);
     for (auto &kv : c->tw_cache) (void)hipFree(kv.second);
+    for (auto &kv : c->small_tabs) (void)hipFree(kv.second);
     for (auto &kv : c->chain_tabs) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.second); }
     c->io_surface.release(); c->io_a.release(); c->io_b.release();
     c->pin_a.release(); c->pin_b.release();
@@ -550,6 +556,19 @@ static int plan_build_tables(caf_plan *p)
     }
 #endif
     if (p->chain) return build_chain_tables<T>(p);
+    if (p->small) {
+        auto key = std::make_pair(p->L, dt);
+        auto it = c->small_tabs.find(key);
+        if (it == c->small_tabs.end()) {
+            void *tw = nullptr;
+            HIPCHK(hipMalloc(&tw, p->L * sizeof(cpx<T>)));
+            k_twiddle<T><<<(unsigned)((p->L + 255) / 256), 256, 0, c->stream>>>((cpx<T> *)tw, p->L, p->L);
+            KCHK();
+            it = c->small_tabs.emplace(key, tw).first;
+        }
+        p->s_twL = it->second;
+        return CAF_OK;
+    }
 #ifdef CAF_MEASURE
     if (p->big) {
         if (!c->bigw256[dt]) {
@@ -610,6 +629,7 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     p->row_begin = row_begin;
     p->rows = row_end - row_begin;
     p->fused = (n == (size_t)F_N);
+    p->small = n <= 512 && measure_env("CAF_SMALL", 1) != 0;  // (CAF_SMALL=0, measurement build: the radix-2 passes over HBM)
     // (CAF_CHAIN=0, measurement build: keep the older tiled65536 / generic paths reachable for comparison)
     p->chain = measure_env("CAF_CHAIN", 1) != 0 && chain_config(n, dtype, &p->clogm, &p->cR);
 #ifdef CAF_MEASURE
@@ -672,7 +692,7 @@ extern "C" int caf_plan_destroy(caf_plan *p)
 
 extern "C" const char *caf_plan_path(const caf_plan *p)
 {
-    return !p ? "" : p->fused ? "fused4096" : p->chain ? "chain" : p->big ? "tiled65536" : "generic";
+    return !p ? "" : p->fused ? "fused4096" : p->chain ? "chain" : p->small ? "small" : p->big ? "tiled65536" : "generic";
 }
 extern "C" size_t caf_plan_rows(const caf_plan *p) { return p ? p->rows : 0; }
 extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
@@ -683,6 +703,13 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
         static thread_local char name[64];
         snprintf(name, sizeof name, "caf::k_chain_rows<%s, %d, %d, %d, 0>", f64 ? "double" : "float", p->clogm, p->cR,
                  chain_nb_v(p->clogm, f64 ? 16 : 8));
+        return name;
+    }
+    if (p->small) {
+        static thread_local char name[64];
+        int lg = 0;
+        while (((size_t)1 << lg) < p->L) ++lg;
+        snprintf(name, sizeof name, "caf::k_small<%s, %d, false>", f64 ? "double" : "float", lg);
         return name;
     }
     if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";  // measurement build
@@ -1063,6 +1090,63 @@ static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_ha
     return CAF_OK;
 }
 
+// n <= 512: lane-group rows (kernels_small.hpp), one launch for the spectra, one for the rows
+template <typename T, int LOGL>
+static int small_launch(caf_plan *p, SmallArgs<T> &a, const void *d_needle, const void *d_hay, size_t batch, size_t total,
+                        void *d_surface, uint64_t *d_ridx, void *d_rval)
+{
+    using G = SmallGeo<LOGL>;
+    caf_ctx *c = p->ctx;
+    const size_t cap = (size_t)c->cu_count * 8;
+    a.sig = (const cpx<T> *)d_hay;
+    a.total = (int)batch;
+    const size_t g0 = (batch + G::RPW - 1) / G::RPW;
+    k_small<T, LOGL, true><<<(unsigned)(g0 < cap ? g0 : cap), G::THREADS, 0, c->stream>>>(a);
+    KCHK();
+    if (total == 0) return CAF_OK;
+    a.sig = (const cpx<T> *)d_needle;
+    a.total = (int)total;
+    a.surface = (T *)d_surface;
+    a.row_idx = d_ridx;
+    a.row_val = (T *)d_rval;
+    int rc;
+    if ((rc = timing_mark(p))) return rc;
+    const size_t g1 = (total + G::RPW - 1) / G::RPW;
+    k_small<T, LOGL, false><<<(unsigned)(g1 < cap ? g1 : cap), G::THREADS, 0, c->stream>>>(a);
+    KCHK();
+    return timing_mark(p);
+}
+
+template <typename T>
+static int surface_dev_small(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
+                             uint64_t *d_ridx, void *d_rval)
+{
+    int rc;
+    if (!p->spec_override && (rc = p->spec.ensure(batch * p->L * sizeof(cpx<T>)))) return rc;
+    SmallArgs<T> a;
+    a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
+    a.twL = (const cpx<T> *)p->s_twL;
+    a.ph = p->d_ph;
+    a.rows = (int)p->rows;
+    a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr;
+    const size_t total = batch * p->rows;
+    int lg = 0;
+    while (((size_t)1 << lg) < p->L) ++lg;
+    switch (lg) {
+    case 1: return small_launch<T, 1>(p, a, d_needle, d_hay, batch, total, d_surface, d_ridx, d_rval);
+    case 2: return small_launch<T, 2>(p, a, d_needle, d_hay, batch, total, d_surface, d_ridx, d_rval);
+    case 3: return small_launch<T, 3>(p, a, d_needle, d_hay, batch, total, d_surface, d_ridx, d_rval);
+    case 4: return small_launch<T, 4>(p, a, d_needle, d_hay, batch, total, d_surface, d_ridx, d_rval);
+    case 5: return small_launch<T, 5>(p, a, d_needle, d_hay, batch, total, d_surface, d_ridx, d_rval);
+    case 6: return small_launch<T, 6>(p, a, d_needle, d_hay, batch, total, d_surface, d_ridx, d_rval);
+    case 7: return small_launch<T, 7>(p, a, d_needle, d_hay, batch, total, d_surface, d_ridx, d_rval);
+    case 8: return small_launch<T, 8>(p, a, d_needle, d_hay, batch, total, d_surface, d_ridx, d_rval);
+    case 9: return small_launch<T, 9>(p, a, d_needle, d_hay, batch, total, d_surface, d_ridx, d_rval);
+    case 10: return small_launch<T, 10>(p, a, d_needle, d_hay, batch, total, d_surface, d_ridx, d_rval);
+    default: return fail(CAF_ERR_STATE, "small path: no kernel for L = %zu", p->L);
+    }
+}
+
 #ifdef CAF_MEASURE
 // n = 32768: four-step tiled path (kernels_big65536.hpp)
 template <typename T>
@@ -1197,6 +1281,7 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
     if (p->dtype == CAF_C128)
         rc = p->fused ? surface_dev_fused<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->chain ? surface_dev_chain<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+             : p->small ? surface_dev_small<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
 #ifdef CAF_MEASURE
              : p->big && p->bigq ? surface_dev_q<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->big ? surface_dev_big<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
@@ -1205,6 +1290,7 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
     else
         rc = p->fused ? surface_dev_fused<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->chain ? surface_dev_chain<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+             : p->small ? surface_dev_small<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
 #ifdef CAF_MEASURE
              : p->big && p->bigq ? surface_dev_q<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->big ? surface_dev_big<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
@@ -1296,7 +1382,7 @@ static int get_host_slot(caf_ctx *c, size_t n, const double *freqs, size_t nfreq
     HCHK(hipMalloc(&s->d_ridx, rows * sizeof(uint64_t)));
     HCHK(hipMalloc(&s->d_rval, rows * rsz));
     HCHK(hipMalloc(&s->d_peak, sizeof(caf_peak)));
-    const size_t spec1 = p->fused ? (size_t)2 * 16 * 256 * esz : p->chain ? p->L * esz : 0;
+    const size_t spec1 = p->fused ? (size_t)2 * 16 * 256 * esz : (p->chain || p->small) ? p->L * esz : 0;
     if (spec1) HCHK(hipMalloc(&s->d_spec, spec1 + 256));
     if (p->chain && p->cR >= 4)
         HCHK(hipMalloc(&s->d_slab, (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, esz, chain_nb_v(p->clogm, esz)) *
@@ -1683,7 +1769,7 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     st->plan = p;
     st->batch = batch;
     st->slots.resize(nslots);
-    const bool private_state = p->fused || p->chain;  // slots (and split branches) own their spectra / scratch
+    const bool private_state = p->fused || p->chain || p->small;  // slots (and split branches) own their spectra / scratch
     // single-surface chains of the tuned n = 4096 path are ONE kernel node (kernels_surf4096.hpp)
     bool one_launch = p->fused && p->rows > 0 && !(flags & CAF_STREAM_THREE_KERNELS) && (batch == 1 || split);
     // One node {staging, spectrum, rows, find_peak} or two {staging + spectrum | rows + find_peak}?  In the one-node
@@ -1701,7 +1787,7 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     const size_t ridx1 = rows * sizeof(uint64_t), rval1 = rows * rsz, surf1 = rows * p->L * rsz;
     const size_t ridx_bytes = batch * ridx1, rval_bytes = batch * rval1, surf_bytes = batch * surf1;
     // per-surface spectrum bytes (+256: the fused path's row-ticket word); split branches get one each
-    const size_t spec1 = p->fused ? (size_t)2 * 16 * 256 * esz : p->chain ? p->L * esz : 0;
+    const size_t spec1 = p->fused ? (size_t)2 * 16 * 256 * esz : (p->chain || p->small) ? p->L * esz : 0;
     const size_t spec_stride = split ? spec1 + 256 : 0;
     const size_t slab1 = p->chain && p->cR >= 4
                              ? (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, esz, chain_nb_v(p->clogm, esz)) *

@@ -230,3 +230,129 @@ def test_multi_stream_error_propagation(eng):
     with pytest.raises(caf.CafError) as ei:
         caf.MultiStream([0], 4095, fr, FS)
     assert ei.value.code == _lib.CAF_ERR_LENGTH
+
+
+# ------------------------------------------------------ short inputs: lane-group rows, n = 1 ... 512 --
+@pytest.mark.parametrize("dtype", ["c128", "c64"])
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512])
+def test_small_path_vs_oracle(n, dtype, eng, oracle):
+    """kernels_small.hpp ("any power of two", xcor_rustfft.rs:2): every n below the chain kernels' range runs as
+    lane-group rows in ONE launch; surface vs the numpy oracle (1e-6 / 1e-3 of the maximum), row argmax where the
+    oracle's row has a clear winner, global peak exact; ragged row counts (rows per workgroup = 256 / max(1, n / 8)
+    does not divide them), several surfaces per launch through the device API."""
+    import torch
+    import caf_cookoff_amd as caf
+    rng = np.random.default_rng(1000 + n)
+    cdt, rdt, tdt = (np.complex128, np.float64, torch.float64) if dtype == "c128" else (np.complex64, np.float32, torch.float32)
+    tol = TOL64 if dtype == "c128" else TOL32
+    fs = 48000
+    F = 37
+    fr = np.linspace(-300.0, 300.0, F)
+    fr[5] = 120.0
+    lag = 0 if n == 1 else int(rng.integers(0, max(1, n // 2)))
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    y = np.roll(x, lag) * np.exp(2j * np.pi * 120.0 * np.arange(n) / fs)
+    y[:lag] = 0
+    x, y = x.astype(cdt), y.astype(cdt)
+    plan = eng.plan(n, fr, fs, dtype=dtype)
+    assert plan.path == "small" and plan.kernel_name.startswith("caf::k_small<")
+    plan.close()
+    surf, ridx, rval, peak = eng.surface_arrays(x, y, fr, fs, dtype=dtype)
+    osurf, oidx, oval = oracle.np_caf_surface(x.astype(np.complex128), y.astype(np.complex128), fr, fs)
+    assert surf.shape == (F, 2 * n) and np.max(np.abs(surf - osurf)) <= tol * osurf.max()
+    part = np.sort(osurf, axis=1)
+    clear = (part[:, -1] - (part[:, -2] if 2 * n > 1 else 0)) > 10 * tol * osurf.max()
+    assert np.array_equal(ridx[clear], oidx[clear])
+    assert np.array_equal(rval, surf[np.arange(F), ridx.astype(np.int64)])      # the row record points at its own maximum
+    assert np.array_equal(ridx, np.argmax(surf, axis=1).astype(np.uint64))      # ... the FIRST one (np.argmax: first max)
+    # batch of 5 through the device API, shard [3, 30)
+    B = 5
+    nd = np.stack([x * (1 + 0.1 * b) for b in range(B)]).astype(cdt)
+    hs = np.stack([np.roll(y, b) for b in range(B)]).astype(cdt)
+    plan = eng.plan(n, fr, fs, dtype=dtype, row_begin=3, row_end=30)
+    dn, dh = torch.from_numpy(nd).cuda(), torch.from_numpy(hs).cuda()
+    ds = torch.full((B, 27, 2 * n), -1.0, dtype=tdt, device="cuda")
+    di = torch.zeros((B, 27), dtype=torch.int64, device="cuda")
+    dv = torch.zeros((B, 27), dtype=tdt, device="cuda")
+    dp = torch.zeros((B, 4), dtype=torch.float64, device="cuda")
+    plan.surface_dev(dn.data_ptr(), dh.data_ptr(), B, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
+    torch.cuda.synchronize()
+    for b in range(B):
+        ob, oi, ov = oracle.np_caf_surface(nd[b].astype(np.complex128), hs[b].astype(np.complex128), fr[3:30], fs)
+        got = ds[b].cpu().numpy()
+        assert np.max(np.abs(got - ob)) <= tol * max(ob.max(), 1e-300)
+        pk = dp[b].cpu().numpy().view(caf.Stream.PEAK_DTYPE)[0]
+        best = int(np.argmax(got.max(axis=1)))
+        assert int(pk["row"]) == 3 + best and int(pk["idx"]) == int(np.argmax(got[best]))
+    plan.close()
+
+
+# ------------------------------------------------------ seeded fuzz against the ORACLE --
+def _fuzz_cases():
+    rng = np.random.default_rng(20261004)
+    sizes = [1, 2, 8, 32, 128, 512, 1024, 2048, 4096, 4096, 4096, 8192, 16384]
+    cases = []
+    for i in range(40):
+        n = int(sizes[i % len(sizes)])
+        dtype = "c128" if (i // 2) % 2 == 0 else "c64"
+        budget = 1 << 21                                     # rows * L per case: keeps the numpy oracle fast
+        nfreq = int(min(rng.integers(1, 701), max(1, budget // (2 * n))))
+        fs = int(rng.choice([8000, 44100, 48000, 250000, 1000000]))
+        batch = int(rng.integers(1, 6)) if nfreq * 2 * n * 5 <= budget * 2 else 1
+        lo = int(rng.integers(0, nfreq))
+        hi = int(rng.integers(lo + 1, nfreq + 1))
+        if i % 3 == 0:
+            lo, hi = 0, nfreq
+        cases.append((i, n, dtype, nfreq, fs, batch, lo, hi))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: f"{c[0]}-n{c[1]}-{c[2]}-F{c[3]}-b{c[5]}-{c[6]}:{c[7]}")
+def test_fuzz_every_path_vs_oracle(case, eng, oracle):
+    """40 seeded random cases over every kernel path (small, chain, tuned n = 4096), both dtypes, nfreq 1...700,
+    five sample rates, batches of 1...5 surfaces, random row shards -- each checked against the numpy ORACLE
+    (np_caf_surface / np_find_peak), never against the HIP path itself: surface within 1e-6 (complex128) / 1e-3
+    (complex64) of its maximum, row argmax equal wherever the oracle's best and second-best lag differ by more than
+    the error bar, shard peak (row, lag) exact when the oracle's winning row leads by more than the error bar."""
+    import torch
+    import caf_cookoff_amd as caf
+    i, n, dtype, nfreq, fs, batch, lo, hi = case
+    rng = np.random.default_rng(555 + i)
+    cdt, tdt = (np.complex128, torch.float64) if dtype == "c128" else (np.complex64, torch.float32)
+    tol = TOL64 if dtype == "c128" else TOL32
+    fr = np.sort(rng.uniform(-0.01 * fs, 0.01 * fs, nfreq))
+    if i % 4 == 1:
+        rng.shuffle(fr)                                      # any order, the list is the row order (mod.rs:135)
+    nd = np.empty((batch, n), dtype=cdt)
+    hs = np.empty((batch, n), dtype=cdt)
+    for b in range(batch):
+        f_true = float(fr[int(rng.integers(lo, hi))])
+        lag = int(rng.integers(0, max(1, n // 4)))
+        x, y = _planted(rng, n, fs, f_true, lag, cdt)
+        nd[b], hs[b] = x, y
+    plan = eng.plan(n, fr, fs, dtype=dtype, row_begin=lo, row_end=hi)
+    rows = hi - lo
+    dn, dh = torch.from_numpy(nd).cuda(), torch.from_numpy(hs).cuda()
+    ds = torch.empty((batch, rows, 2 * n), dtype=tdt, device="cuda")
+    di = torch.zeros((batch, rows), dtype=torch.int64, device="cuda")
+    dv = torch.zeros((batch, rows), dtype=tdt, device="cuda")
+    dp = torch.zeros((batch, 4), dtype=torch.float64, device="cuda")
+    plan.surface_dev(dn.data_ptr(), dh.data_ptr(), batch, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
+    torch.cuda.synchronize()
+    for b in range(batch):
+        osurf, oidx, oval = oracle.np_caf_surface(nd[b].astype(np.complex128), hs[b].astype(np.complex128), fr[lo:hi], fs)
+        mx = osurf.max()
+        got, gi, gv = ds[b].cpu().numpy(), di[b].cpu().numpy(), dv[b].cpu().numpy()
+        assert np.max(np.abs(got - osurf)) <= tol * mx, f"case {i} surface {b}"
+        if 2 * n > 1:
+            part = np.partition(osurf, -2, axis=1)
+            clear = (part[:, -1] - part[:, -2]) > 4 * tol * mx
+            assert np.array_equal(gi[clear], oidx[clear].astype(np.int64)), f"case {i} surface {b}: row argmax"
+        assert np.max(np.abs(gv.astype(np.float64) - oval)) <= tol * mx
+        pk = dp[b].cpu().numpy().view(caf.Stream.PEAK_DTYPE)[0]
+        order = np.sort(oval)
+        if len(order) == 1 or order[-1] - order[-2] > 4 * tol * mx:
+            of, oi = oracle.np_find_peak(fr[lo:hi], oidx, oval)
+            assert (pk["freq"], int(pk["idx"])) == (of, oi), f"case {i} surface {b}: shard peak"
+            assert int(pk["row"]) == lo + int(np.argmax(oval))
+    plan.close()
