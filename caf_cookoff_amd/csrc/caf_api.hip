@@ -457,8 +457,8 @@ extern "C" int caf_xcor_c64(caf_ctx *c, const float *a, const float *b, size_t n
 // ----------------------------------------------------------- chain path set-up --
 // Which padded lengths the LDS-resident chain kernels (kernels_chain.hpp) cover: L = 2n = R * M
 // with one chain of M points (plus its padding and twiddle tables) inside 160 KiB of LDS:
-//   complex64:  M <= 16384  -> n = 1024 ... 16384 (R = 2), 32768 (R = 4, BASELINE configs[3]), 65536 (R = 8)
-//   complex128: M <=  8192  -> n = 1024 ... 8192 (R = 2), 16384 (R = 4), 32768 (R = 8)
+//   complex64:  M <= 16384  -> n = 1024 ... 16384 (R = 2), 32768 (R = 4, BASELINE configs[3]), 65536 (R = 8), 131072 (R = 16)
+//   complex128: M <=  8192  -> n = 1024 ... 8192 (R = 2), 16384 (R = 4), 32768 (R = 8), 65536 (R = 16)
 // n = 4096 keeps its tuned kernels (kernels_seq4096.hpp / kernels_duo4096.hpp).
 static bool chain_config(size_t n, int dtype, int *logm, int *R)
 {
@@ -471,6 +471,7 @@ static bool chain_config(size_t n, int dtype, int *logm, int *R)
     if (n <= m_max) { M = n; *R = 2; }
     else if (n / 2 <= m_max) { M = n / 2; *R = 4; }
     else if (n / 4 <= m_max) { M = n / 4; *R = 8; }
+    else if (n / 8 <= m_max) { M = n / 8; *R = 16; }
     else return false;
     int l = 0;
     while (((size_t)1 << l) < M) ++l;
@@ -497,11 +498,11 @@ static bool chain_config(size_t n, int dtype, int *logm, int *R)
         const int logm_ = (logm), R_rt = (R);                                                          \
         if constexpr (sizeof(T) == 4) {                                                                \
             CHAIN_CASE(10, 2, STMT) CHAIN_CASE(11, 2, STMT) CHAIN_CASE(13, 2, STMT) CHAIN_CASE(14, 2, STMT) \
-            CHAIN_CASE(14, 4, STMT) CHAIN_CASE(14, 8, STMT) CHAIN_CASES_MEASURE_F32(STMT)              \
+            CHAIN_CASE(14, 4, STMT) CHAIN_CASE(14, 8, STMT) CHAIN_CASE(14, 16, STMT) CHAIN_CASES_MEASURE_F32(STMT) \
             return fail(CAF_ERR_STATE, "chain path: no kernel for M=2^%d R=%d", logm_, R_rt);           \
         } else {                                                                                       \
             CHAIN_CASE(10, 2, STMT) CHAIN_CASE(11, 2, STMT) CHAIN_CASE(13, 2, STMT) CHAIN_CASE(13, 4, STMT) \
-            CHAIN_CASE(13, 8, STMT)                                                                    \
+            CHAIN_CASE(13, 8, STMT) CHAIN_CASE(13, 16, STMT)                                           \
             return fail(CAF_ERR_STATE, "chain path: no kernel for M=2^%d R=%d", logm_, R_rt);           \
         }                                                                                              \
     } while (0)

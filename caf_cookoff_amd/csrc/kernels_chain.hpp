@@ -2,7 +2,7 @@
 //
 // Same mathematics as kernels_seq4096.hpp (mod.rs:121-166 with FFT(haystack) hoisted and every
 // transform a positive-exponent one), for any padded length L = 2n = R * M that splits into
-// R in {2, 4, 8} "chains" of M = 2^LOGM points, M * sizeof(complex) <= ~128 KiB so ONE chain lives
+// R in {2, 4, 8, 16} "chains" of M = 2^LOGM points, M * sizeof(complex) <= ~128 KiB so ONE chain lives
 // in a workgroup's LDS:
 //
 //   forward, decimation in frequency over the first radix-R stage: bins k = R k' + r,
@@ -36,6 +36,9 @@
 // that slab once each way, instead of three passes over a work row (kernels_big65536.hpp).
 // R = 8 (n = 65536 complex64, n = 32768 complex128): the same with chain pairs (r', r'+4) and two
 // radix-4 combinations at the end; six slab arrays.
+// R = 16 (n = 131072 complex64, n = 65536 complex128): all sixteen chain outputs go to the workgroup's slab
+// (2 MiB per workgroup) and the SAME workgroup then streams them back lag by lag through one radix-16
+// butterfly -- a compute phase and a memory phase per row, which different workgroups run at different times.
 #pragma once
 #include "kernels_seq4096.hpp"
 
@@ -82,7 +85,7 @@ constexpr size_t chain_wg_per_cu_v(int logm, size_t csize, int nb = 1)
     return per_cu < 1 ? 1 : per_cu;
 }
 // scratch-slab arrays per workgroup: R = 4: a, b;  R = 8: P0/aP, Q0/bP, aQ, bQ, P1, Q1
-constexpr int chain_slab_arrays_v(int R) { return R == 8 ? 6 : 2; }
+constexpr int chain_slab_arrays_v(int R) { return R == 16 ? 16 : R == 8 ? 6 : 2; }  // R = 16: every chain output
 // butterflies per thread of the row kernel (see ChainLane: two was measured and lost)
 constexpr int chain_nb_v(int, size_t) { return 1; }
 template <typename T, int LOGM>
@@ -110,9 +113,10 @@ __global__ void k_chain_tables(cpx<T> *__restrict__ twM, cpx<T> *__restrict__ th
 //   R = 4: [112] w^M                              (second half of the needle)
 //   R = 8: [176 + 3 r' + (j-1)] kappa_{r',j} = w^(M j) * e^{-2 pi i j r' / 8}, r' < 4, j = 1..3
 //          (quarters 1..3 of the needle, with the pruned radix-8 input stage's constants folded in)
+//   R = 16: [304 + 7 r' + (j-1)] kappa_{r',j} = w^(M j) * e^{-2 pi i j r' / 16}, r' < 8, j = 1..7
 // every entry from one f64 sincos of the exact phase product (never an f32
 // recurrence), w = e^{j ph}, ph = ((2 PI) f)(1/fs) as mod.rs:54-56.
-constexpr int chain_ph_v(int R) { return R == 8 ? 256 : 128; }
+constexpr int chain_ph_v(int R) { return R == 16 ? 512 : R == 8 ? 256 : 128; }
 template <typename T>
 __global__ void k_chain_phasors(const double *__restrict__ ph, int nrows, int M, int R, cpx<T> *__restrict__ tab)
 {
@@ -135,6 +139,10 @@ __global__ void k_chain_phasors(const double *__restrict__ ph, int nrows, int M,
         const int rp = (e - 176) / 3, j = (e - 176) % 3 + 1;
         mult = (double)M * (double)j;
         rot = (double)(j * rp) / 8.0;
+    } else if (R == 16 && e >= 304 && e < 360) {
+        const int rp = (e - 304) / 7, j = (e - 304) % 7 + 1;
+        mult = (double)M * (double)j;
+        rot = (double)(j * rp) / 16.0;
     }
     double s, c, s2, c2;
     sincos(p * mult, &s, &c);
@@ -426,10 +434,10 @@ __device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[
     using C = cpx<T>;
     constexpr int W = ChainGeo<LOGM>::W, M = ChainGeo<LOGM>::M;
     constexpr int NQ = R / 2;                                   // nonzero quarters / halves of the padded needle
-    constexpr int GQ = (R == 2) ? 4 : (sizeof(T) == 4 ? 2 : 4);  // register rows per fetch group (two groups in flight)
+    constexpr int GQ = (R == 2) ? 4 : (R == 16) ? 1 : (sizeof(T) == 4 ? 2 : 4);  // register rows per fetch group (two groups in flight)
     const C *psA = ph + 48 + 16 * rA, *psB = ph + 48 + 16 * rB;
     const unsigned voff = (unsigned)(beta * sizeof(C));
-    C k1 = C{T(1), T(0)}, k2 = k1, k3 = k1;
+    C k1 = C{T(1), T(0)}, k2 = k1, k3 = k1, k4 = k1, k5 = k1, k6 = k1, k7 = k1;
     constexpr bool RT = (ABL & 256) != 0;  // rA is a run-time value (looped R = 4 rows, measurement variant)
     if constexpr (R == 4) {
         k1 = ph[112];  // w^M
@@ -439,6 +447,10 @@ __device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[
         k1 = ph[176 + 3 * rA];
         k2 = ph[176 + 3 * rA + 1];
         k3 = ph[176 + 3 * rA + 2];
+    }
+    if constexpr (R == 16) {             // kappa_{rA, 1..7}
+        const C *kp = ph + 304 + 7 * rA;
+        k1 = kp[0]; k2 = kp[1]; k3 = kp[2]; k4 = kp[3]; k5 = kp[4]; k6 = kp[5]; k7 = kp[6];
     }
     C a[2][GQ][NQ];
     auto fetch = [&](int grp) {
@@ -476,10 +488,17 @@ __device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[
                     vA[q] = cmul_conj(rA == 0 ? x + b : sub_i(x, b), psA[q]);
                     vB[q] = cmul_conj(rA == 0 ? x - b : add_i(x, b), psB[q]);
                 }
-            } else {
+            } else if constexpr (R == 8) {
                 // x_rA = E + O, x_(rA+4) = E - O;  E = a0 + kappa_2 a2,  O = kappa_1 a1 + kappa_3 a3
                 const C E = cfma(x, a[grp & 1][u][2], k2);
                 const C O = cfma(cmul(a[grp & 1][u][1], k1), a[grp & 1][u][3], k3);
+                vA[q] = cmul_conj(E + O, psA[q]);
+                vB[q] = cmul_conj(E - O, psB[q]);
+            } else {
+                // R = 16: x_rA = E + O, x_(rA+8) = E - O;  E = sum of the even, O of the odd eighths kappa_j a_j
+                const C(&aa)[NQ] = a[grp & 1][u];
+                const C E = cfma(cfma(cfma(x, aa[2], k2), aa[4], k4), aa[6], k6);
+                const C O = cfma(cfma(cfma(cmul(aa[1], k1), aa[3], k3), aa[5], k5), aa[7], k7);
                 vA[q] = cmul_conj(E + O, psA[q]);
                 vB[q] = cmul_conj(E - O, psB[q]);
             }
@@ -536,6 +555,17 @@ __device__ __forceinline__ void chain_input_one(cpx<T> (&v)[16], const __amdgpu_
             const C E = cfma(x, a2, ph[176 + 3 * rp + 1]);
             const C O = cfma(cmul(a1, ph[176 + 3 * rp]), a3, ph[176 + 3 * rp + 2]);
             x = r < 4 ? E + O : E - O;
+        }
+        if constexpr (R == 16) {  // the f = 0 row's kappa_{r', j} = e^{-2 pi i j r'/16}; chains r'+8 take E - O
+            const C *kp = ph + 304 + 7 * (r & 7);
+            C E = x, O = C{T(0), T(0)};
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+                const C aj = bload(rs_sig, voff, (unsigned)((j * M + W * q) * sizeof(C)), (C *)nullptr);
+                if (j & 1) O = cfma(O, aj, kp[j - 1]);
+                else E = cfma(E, aj, kp[j - 1]);
+            }
+            x = r < 8 ? E + O : E - O;
         }
         v[q] = cmul_conj(x, ps[q]);
     }
@@ -607,7 +637,7 @@ __device__ __forceinline__ void chain_run(cpx<T> (&v)[NB][16], const ChainLane<T
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if constexpr (R != 8 && !(ABL & 256)) {  // r is a compile-time constant after inlining: chain 0 keeps its cheaper twiddle form
+    if constexpr (R < 8 && !(ABL & 256)) {  // r is a compile-time constant after inlining: chain 0 keeps its cheaper twiddle form
         if (r) {
             L.inverse(v, [&](int b, int k, C x) { const TwFold<T> fpost(L.tw[b], post[b]); return twA_k(x, k, L.tw[b], fpost); });
         } else {
@@ -722,7 +752,47 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
                 if constexpr (ABL & 4) { C x = C{T(i), T(arr)}; keep(x); return x; }
                 return bload(rs_slab, (unsigned)(L.beta[b] * sizeof(C)), (unsigned)((arr * 16 + i) * W * sizeof(C)), (C *)nullptr);
             };
-            if constexpr (R == 8 || (ABL & 256) != 0) {
+            if constexpr (R == 16) {
+                // COMPUTE PHASE: the eight chain pairs (r', r'+8) as iterations of a run-time loop (the chain code exists
+                // once, as for R = 8); every chain output y'_r goes to slab array r.  MEMORY PHASE: lag by lag,
+                // c[m' + M j] = sum_r W_16^(j r) W_256^(i r) y'_r[m'],  m' = beta + W i: sixteen coalesced slab reads,
+                // the W_256 twiddles from a table that takes the (now idle) chain's first 256 LDS positions, one
+                // radix-16 butterfly, |.|^2, argmax, sixteen coalesced surface stores.
+                static_assert(NB == 1, "looped rows are written for one butterfly per thread");
+                C cur[1][16], oth[1][16];
+#pragma clang loop unroll(disable)
+                for (int it = 0; it < 8; ++it) {
+                    const int rp = __builtin_amdgcn_readfirstlane(it);
+                    chain_input_pair<T, LOGM, R, ABL>(cur[0], oth[0], rs_sig, rp, rp + 8, L.beta[0], ph);
+#pragma clang loop unroll(disable)
+                    for (int c = 0; c < 2; ++c) {
+                        const int r = __builtin_amdgcn_readfirstlane(rp + 8 * c);
+                        chain_run<T, LOGM, R, NB, ABL>(cur, L, A, rs_spec, r, pb);
+                        const unsigned so = (unsigned)(r * 16 * W * sizeof(C));
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            bstore(rs_slab, (unsigned)(L.beta[0] * sizeof(C)), so + (unsigned)(i * W * sizeof(C)), cur[0][i]);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { const C t = cur[0][i]; cur[0][i] = oth[0][i]; oth[0][i] = t; }
+                    }
+                }
+                __syncthreads();  // every wave is done with the chain: its LDS becomes the W_256 table
+                if (L.t < 256) L.Lc[L.t] = A.twM[L.t * (M / 256)];
+                __syncthreads();
+#pragma clang loop unroll(disable)
+                for (int i = 0; i < 16; ++i) {
+                    C z[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        z[r] = bload(rs_slab, (unsigned)(L.beta[0] * sizeof(C)), (unsigned)((r * 16 + i) * W * sizeof(C)), (C *)nullptr);
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) z[r] = cmul(z[r], L.Lc[(i * r) & 255]);
+                    dft16(z);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) emit(j, i, 0, z[j]);
+                }
+                __syncthreads();  // the table's positions belong to the next row's chain again
+            } else if constexpr (R == 8 || (ABL & 256) != 0) {
                 // LOOPED form (R = 8 always; R = 4 as a measurement variant, where it is 1-2 % slower than the unrolled
                 // form below; R = 8 gains 14 %: 2.10 vs 2.44 ms per 2048 x 131072 complex64 rows, 74 vs 206 spills): the R/2 chain pairs are iterations of a run-time loop and the two chains of a pair
                 // iterations of an inner one, so the chain code (input stage, forward, spectrum product, inverse:

@@ -30,13 +30,17 @@ struct SmallGeo {
     static constexpr int PT = L / TPR;                // points per lane (16, or L when L < 16)
     static constexpr int THREADS = 256;
     static constexpr int RPW = THREADS / TPR;         // rows per workgroup
+    // LDS elements per row: two buffers of L points + one pad element, so that the lanes of a wave that own
+    // DIFFERENT rows (TPR < 64) do not all hit the same bank (an unpadded stride of 2 L complex is a multiple of
+    // the 256-byte bank period for every L >= 16: a 64-way conflict when one lane owns a row)
+    static constexpr int ROWSTRIDE = 2 * L + 1;
 };
 
 template <typename T, int LOGL>
 constexpr size_t small_lds_bytes()
 {
     using G = SmallGeo<LOGL>;
-    return ((size_t)G::L + 2 * (size_t)G::RPW * G::L) * sizeof(cpx<T>);
+    return ((size_t)G::L + (size_t)G::RPW * G::ROWSTRIDE) * sizeof(cpx<T>);
 }
 
 // in-place DFT_R (positive exponent, natural order) of v[0 .. R-1]
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(SmallGeo<LOGL>::THREADS) void k_small(const SmallAr
     __shared__ __attribute__((aligned(16))) unsigned char smem[small_lds_bytes<T, LOGL>()];
     C *const twl = reinterpret_cast<C *>(smem);
     const int tid = threadIdx.x, rw = tid / TPR, tl = tid % TPR;
-    C *const bx = twl + L + (size_t)rw * 2 * L, *const by = bx + L;
+    C *const bx = twl + L + (size_t)rw * G::ROWSTRIDE, *const by = bx + L;
     for (int i = tid; i < L; i += G::THREADS) twl[i] = A.twL[i];
     __syncthreads();
     const int ngroups = (A.total + G::RPW - 1) / G::RPW;
@@ -174,13 +178,32 @@ __global__ __launch_bounds__(SmallGeo<LOGL>::THREADS) void k_small(const SmallAr
             C *c = small_idft<T, LOGL>(res, oth, twl, tl);
             T bv = T(0);
             uint32_t bi = 0u;
-            T *const out = (A.surface && live) ? A.surface + (size_t)g * L : nullptr;
+            // the magnitudes go to the row's other (now free) buffer first and leave from there wave-wide: the
+            // 64 / TPR rows of a wave are adjacent in the surface, so the wave stores one contiguous run with
+            // consecutive lanes on consecutive lags (a lane storing its own row's values directly would write 4 or
+            // 8 bytes at a stride of a whole row)
+            C *const free_buf = c == bx ? by : bx;
+            T *const mg = reinterpret_cast<T *>(free_buf);
 #pragma unroll
             for (int i = 0; i < PT; ++i) {
                 const int k = tl + TPR * i;
                 const T m = norm_sqr(c[k]);  // mod.rs:147
-                if (out) out[k] = m;
+                mg[k] = m;
                 if (m > bv) { bv = m; bi = (uint32_t)k; }  // first strictly greater (mod.rs:148-151); k ascends with i
+            }
+            if (A.surface) {
+                wave_lds_fence();
+                constexpr int RPWV = 64 / TPR;                     // rows per wave
+                const int wrow0 = (tid >> 6) * RPWV;               // first row of this wave inside the workgroup
+                const int g0 = grp * G::RPW + wrow0;               // ... and in the launch
+                const T *const mg0 = reinterpret_cast<const T *>(twl + L + (size_t)wrow0 * G::ROWSTRIDE + (free_buf - bx));
+                T *const out0 = A.surface + (size_t)g0 * L;
+                const int lane = tid & 63;
+#pragma unroll
+                for (int e0 = 0; e0 < RPWV * L; e0 += 64) {
+                    const int e = e0 + lane, rr = e / L, k = e % L;
+                    if (g0 + rr < A.total) out0[e] = mg0[(size_t)rr * (G::ROWSTRIDE * (sizeof(C) / sizeof(T))) + k];
+                }
             }
             // reduce over the row's TPR lanes (a power of two, aligned inside the wave); equal values keep the lower lag
 #pragma unroll

@@ -619,9 +619,10 @@ def test_tiled65536_via_measurement_build(meng, oracle, monkeypatch, dtype):
 
 
 def test_generic_path_still_covers_other_big_sizes(eng, oracle):
-    """n = 65536 (L = 131072) exceeds every LDS-resident form: generic HBM-pass path."""
+    """n = 131072 complex128 (L = 262144) exceeds every LDS-resident form (sixteen chains of 8192 points end at
+    n = 65536): generic HBM-pass path."""
     from caf_cookoff_amd.synth import make_pair
-    n = 65536
+    n = 131072
     s0, s1, lag, fo = make_pair(n=n, seed=79, lag=33, foffset=5.0)
     fr = np.array([4.5, 5.0, 5.5])
     plan = eng.plan(n, fr, FS)

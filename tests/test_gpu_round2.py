@@ -252,7 +252,8 @@ CHAIN_CASES = [(1024, "c128", "caf::k_chain_rows<double, 10, 2, 1, 0>"), (2048, 
                (1024, "c64", "caf::k_chain_rows<float, 10, 2, 1, 0>"), (2048, "c64", "caf::k_chain_rows<float, 11, 2, 1, 0>"),
                (8192, "c64", "caf::k_chain_rows<float, 13, 2, 1, 0>"), (16384, "c64", "caf::k_chain_rows<float, 14, 2, 1, 0>"),
                (32768, "c64", "caf::k_chain_rows<float, 14, 4, 1, 0>"), (32768, "c128", "caf::k_chain_rows<double, 13, 8, 1, 0>"),
-               (65536, "c64", "caf::k_chain_rows<float, 14, 8, 1, 0>")]
+               (65536, "c64", "caf::k_chain_rows<float, 14, 8, 1, 0>"), (65536, "c128", "caf::k_chain_rows<double, 13, 16, 1, 0>"),
+               (131072, "c64", "caf::k_chain_rows<float, 14, 16, 1, 0>")]
 
 
 @pytest.mark.parametrize("n,dtype,kernel", CHAIN_CASES, ids=lambda v: str(v) if not isinstance(v, str) or len(v) < 6 else None)

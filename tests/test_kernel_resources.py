@@ -29,7 +29,7 @@ def _usage():
 def test_product_row_kernels_have_no_vgpr_spills_and_expected_occupancy():
     usage = _usage()
     f64 = usage["_ZN3caf10k_seq_rowsIdLi0ELi0ELi15EEEvNS_9FusedArgsIT_EEPKNS_3cpxIS2_EE"]
-    f32 = usage["_ZN3caf10k_duo_rowsIfLi0EEEvNS_9FusedArgsIT_EEPKNS_3cpxIS2_EE"]
+    f32 = usage["_ZN3caf10k_duo_rowsIfLi0ENS_5DuoIoIfEEEEvNS_9FusedArgsIT_EEPKNS_3cpxIS4_EE"]
     assert int(f64["VGPRs Spill"]) == 0 and int(f64["Occupancy [waves/SIMD]"]) == 2
     assert int(f64["LDS Size [bytes/block]"]) * 2 <= 160 * 1024       # two workgroups per CU
     assert int(f32["VGPRs Spill"]) == 0 and int(f32["Occupancy [waves/SIMD]"]) == 3
@@ -55,9 +55,9 @@ def test_chain_kernels_register_shape():
             continue
         seen += 1
         is_f64 = "k_chain_rowsId" in name
-        r = 8 if "ELi8ELi1ELi0E" in name else 4 if "ELi4ELi1ELi0E" in name else 2
+        r = 16 if "ELi16ELi1ELi0E" in name else 8 if "ELi8ELi1ELi0E" in name else 4 if "ELi4ELi1ELi0E" in name else 2
         assert int(f["LDS Size [bytes/block]"]) <= 160 * 1024
         assert int(f["Occupancy [waves/SIMD]"]) == (2 if is_f64 else 4), name
-        limit = {2: 30, 4: 30 if is_f64 else 50, 8: 70 if is_f64 else 90}[r]
+        limit = {2: 30, 4: 30 if is_f64 else 50, 8: 70 if is_f64 else 90, 16: 10 if is_f64 else 60}[r]
         assert int(f["VGPRs Spill"]) <= limit, (name, f["VGPRs Spill"])
-    assert seen == 11  # 5 complex128 + 6 complex64 instantiations
+    assert seen == 13  # 6 complex128 + 7 complex64 instantiations (R = 16: n = 65536 complex128, n = 131072 complex64)
