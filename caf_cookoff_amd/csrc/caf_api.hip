@@ -34,6 +34,7 @@
 #include "kernels_big65536.hpp"  // four-step tiled n = 32768 path of round 1 (CAF_CHAIN=0), superseded by the chain path
 #include "kernels_q65536.hpp"
 #include "kernels_ablate.hpp"     // arithmetic-only memory policies (issue ceilings; wrong results)
+#include "kernels_r32.hpp"        // configs[3] with 32 points per thread (CAF_R32=1): VERDICT r02 item 4, measured and rejected or promoted
 #endif
 
 using namespace caf;
@@ -180,6 +181,8 @@ struct caf_plan {
     size_t nfreq_total = 0, row_begin = 0, rows = 0;
     bool fused = false;
     bool big = false;           // n == 32768 complex128: four-step tiled path
+    bool r32 = false;           // measurement build, CAF_R32=1: n = 32768 complex64 with 32 points per thread (kernels_r32.hpp)
+    void *r32_tw = nullptr, *r32_th = nullptr;
     bool small = false;         // n <= 512: lane-group rows (kernels_small.hpp)
     void *s_twL = nullptr;      //   ... its W_L table (borrowed from the ctx cache)
     bool chain = false;         // LDS-resident chain path (kernels_chain.hpp): R chains of 2^logm points
@@ -556,6 +559,19 @@ static int plan_build_tables(caf_plan *p)
         return CAF_OK;
     }
 #endif
+#ifdef CAF_MEASURE
+    if (p->r32) {
+        HIPCHK(hipMalloc(&p->r32_tw, (size_t)W_M * sizeof(cpx<T>)));
+        HIPCHK(hipMalloc(&p->r32_th, (size_t)3 * W_T * sizeof(cpx<T>)));
+        k_r32_tables<T><<<W_M / 256, 256, 0, c->stream>>>((cpx<T> *)p->r32_tw, (cpx<T> *)p->r32_th);
+        KCHK();
+        const size_t nr = p->rows + 1;
+        HIPCHK(hipMalloc(&p->d_phasor, nr * W_PH * sizeof(cpx<T>)));
+        k_r32_phasors<T><<<(unsigned)((nr * W_PH + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows, (cpx<T> *)p->d_phasor);
+        KCHK();
+        return CAF_OK;
+    }
+#endif
     if (p->chain) return build_chain_tables<T>(p);
     if (p->small) {
         auto key = std::make_pair(p->L, dt);
@@ -633,6 +649,7 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     p->small = n <= 512 && measure_env("CAF_SMALL", 1) != 0;  // (CAF_SMALL=0, measurement build: the radix-2 passes over HBM)
     // (CAF_CHAIN=0, measurement build: keep the older tiled65536 / generic paths reachable for comparison)
     p->chain = measure_env("CAF_CHAIN", 1) != 0 && chain_config(n, dtype, &p->clogm, &p->cR);
+    p->r32 = p->chain && n == 32768 && dtype == CAF_C64 && measure_env("CAF_R32", 0) >= 1;
 #ifdef CAF_MEASURE
     p->big = !p->chain && (n == (size_t)B_N);  // only reachable with CAF_CHAIN=0
 #endif
@@ -683,6 +700,8 @@ extern "C" int caf_plan_destroy(caf_plan *p)
     if (p->d_freqs) (void)hipFree(p->d_freqs);
     if (p->d_ph) (void)hipFree(p->d_ph);
     if (p->d_phasor) (void)hipFree(p->d_phasor);
+    if (p->r32_tw) (void)hipFree(p->r32_tw);
+    if (p->r32_th) (void)hipFree(p->r32_th);
     p->spec.release(); p->wx.release(); p->wy.release(); p->hx.release(); p->hy.release();
     p->bwork.release(); p->bhwork.release(); p->bpart_val.release(); p->bpart_idx.release();
     p->slab.release();
@@ -700,6 +719,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
 {
     if (!p) return "";
     const bool f64 = p->dtype == CAF_C128;
+    if (p->r32) return "caf::k_r32_rows<float>";
     if (p->chain) {
         static thread_local char name[64];
         snprintf(name, sizeof name, "caf::k_chain_rows<%s, %d, %d, %d, 0>", f64 ? "double" : "float", p->clogm, p->cR,
@@ -1016,6 +1036,57 @@ static int surface_dev_q(caf_plan *p, const void *d_needle, const void *d_hay, s
 }
 #endif  // CAF_MEASURE
 
+#ifdef CAF_MEASURE
+// n = 32768 complex64 with 32 points per thread (kernels_r32.hpp)
+static int surface_dev_r32(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
+                           uint64_t *d_ridx, void *d_rval)
+{
+    using T = float;
+    caf_ctx *c = p->ctx;
+    const size_t total = batch * p->rows;
+    int rc;
+    if (!p->spec_override && (rc = p->spec.ensure(batch * (size_t)W_L * sizeof(cpx<T>)))) return rc;
+    R32Args<T> a;
+    a.twM = (const cpx<T> *)p->r32_tw;
+    a.th = (const cpx<T> *)p->r32_th;
+    a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
+    a.rows = (int)p->rows;
+    a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr; a.slab = nullptr;
+    const cpx<T> *phasor = (const cpx<T> *)p->d_phasor;
+    const size_t cap = (size_t)c->cu_count;
+    a.sig = (const cpx<T> *)d_hay;
+    a.total = (int)batch;
+    {
+        const size_t want = (size_t)W_R * batch;
+        k_r32_prepare<T><<<(unsigned)(want < cap ? want : cap), W_T, 0, c->stream>>>(a, phasor);
+    }
+    KCHK();
+    if (total == 0) return CAF_OK;
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
+    if (!p->slab_override && (rc = p->slab.ensure(cap * 64 * W_T * sizeof(cpx<T>)))) return rc;
+    a.slab = (cpx<T> *)(p->slab_override ? p->slab_override : p->slab.p);
+    a.sig = (const cpx<T> *)d_needle;
+    a.total = (int)total;
+    a.surface = (T *)d_surface;
+    a.row_idx = d_ridx;
+    a.row_val = (T *)d_rval;
+    if ((rc = timing_mark(p))) return rc;
+    switch ((int)measure_env("CAF_R32", 1)) {  // 1: the kernel; > 1: 1 + ablation mask (wrong results, timing only)
+    case 1: k_r32_rows<T, 0><<<grid, W_T, 0, c->stream>>>(a, phasor); break;
+    case 2: k_r32_rows<T, 1><<<grid, W_T, 0, c->stream>>>(a, phasor); break;    // no slab
+    case 3: k_r32_rows<T, 2><<<grid, W_T, 0, c->stream>>>(a, phasor); break;    // no surface stores
+    case 16: k_r32_rows<T, 15><<<grid, W_T, 0, c->stream>>>(a, phasor); break;  // no global memory
+    case 32: k_r32_rows<T, 31><<<grid, W_T, 0, c->stream>>>(a, phasor); break;  // ... and no workgroup barriers
+    case 33: k_r32_rows<T, 32><<<grid, W_T, 0, c->stream>>>(a, phasor); break;  // half the slab traffic (only b)
+    case 102: k_r32_rows<T, 0, 2><<<grid, W_T, 0, c->stream>>>(a, phasor); break;
+    case 104: k_r32_rows<T, 0, 4><<<grid, W_T, 0, c->stream>>>(a, phasor); break;
+    default: return fail(CAF_ERR_BAD_ARG, "CAF_R32=%ld: no such variant", measure_env("CAF_R32", 1));
+    }
+    KCHK();
+    return timing_mark(p);
+}
+#endif
+
 // LDS-resident chain path (kernels_chain.hpp)
 template <typename T>
 static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
@@ -1290,6 +1361,9 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
                       : surface_dev_generic<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     else
         rc = p->fused ? surface_dev_fused<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+#ifdef CAF_MEASURE
+             : p->r32 ? surface_dev_r32(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
+#endif
              : p->chain ? surface_dev_chain<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->small ? surface_dev_small<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
 #ifdef CAF_MEASURE

@@ -356,3 +356,43 @@ def test_fuzz_every_path_vs_oracle(case, eng, oracle):
             assert (pk["freq"], int(pk["idx"])) == (of, oi), f"case {i} surface {b}: shard peak"
             assert int(pk["row"]) == lo + int(np.argmax(oval))
     plan.close()
+
+
+# ------------------------------------------------------ configs[3] with 32 points per thread (measured and rejected) --
+def test_r32_variant_matches_oracle_and_product_kernel(eng, oracle, monkeypatch):
+    """kernels_r32.hpp (16384 = 32 x 32 x 16, 512 threads, two LDS exchanges per transform) lives
+    in the MEASUREMENT library (CAF_R32=1): parity-green against the oracle, row argmax and peak equal to the product
+    chain kernel's on a multi-row launch that wraps the persistent grid (300 rows > 256 workgroups), and
+    bit-identical from run to run.  It runs at the product kernel's speed, not faster -- DESIGN.md section 5."""
+    import torch
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.synth import make_pair
+    monkeypatch.setenv("CAF_R32", "1")
+    meng = caf.Engine(0, lib=caf.MEASURE_LIB_PATH)
+    n = 32768
+    s0, s1, lag, fo = make_pair(n=n, seed=5, lag=777, foffset=-31.5, dtype=np.complex64)
+    fr = np.concatenate([np.array([-40.0, -32.0, -31.5, -31.0, 0.0, 31.5, 977.25]), np.linspace(-60.0, 60.0, 293)])
+    plan = meng.plan(n, fr, FS, dtype="c64")
+    assert plan.kernel_name == "caf::k_r32_rows<float>"
+    dn, dh = torch.from_numpy(s0[None]).cuda(), torch.from_numpy(s1[None]).cuda()
+    outs = []
+    for rep in range(2):
+        ds = torch.empty((1, len(fr), 2 * n), dtype=torch.float32, device="cuda")
+        di = torch.zeros((1, len(fr)), dtype=torch.int64, device="cuda")
+        dv = torch.zeros((1, len(fr)), dtype=torch.float32, device="cuda")
+        dp = torch.zeros((1, 4), dtype=torch.float64, device="cuda")
+        plan.surface_dev(dn.data_ptr(), dh.data_ptr(), 1, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
+        meng.synchronize()
+        outs.append((ds[0].cpu().numpy(), di[0].cpu().numpy(), dv[0].cpu().numpy(), dp.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[0, 0]))
+    plan.close()
+    meng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    surf, ridx, rval, pk = outs[0]
+    rows = [0, 1, 2, 3, 6, 150, 255, 256, 257, 299]           # rows on both sides of the grid wrap
+    osurf, oidx, oval = oracle.np_caf_surface(s0.astype(np.complex128), s1.astype(np.complex128), fr[rows], FS)
+    mx = max(osurf.max(), float(surf.max()))
+    assert np.max(np.abs(surf[rows] - osurf)) <= TOL32 * mx
+    _, ridx0, rval0, pk0 = eng.surface_arrays(s0, s1, fr, FS, want_surface=False, dtype="c64")
+    part = np.partition(surf.astype(np.float64), -2, axis=1)
+    clear = (part[:, -1] - part[:, -2]) > 1e-4 * mx
+    assert np.array_equal(ridx[clear], ridx0[clear].astype(np.int64)) and (pk["freq"], int(pk["idx"])) == (pk0.freq, pk0.idx) == (-31.5, lag)

@@ -14,7 +14,7 @@ n, F, dtype = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 batch = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 nosurf = len(sys.argv) > 5 and sys.argv[5] == "nosurf"
 import os
-eng = caf.Engine(0, lib=caf.MEASURE_LIB_PATH if any(k.startswith("CAF_CHAIN") for k in os.environ) else None)
+eng = caf.Engine(0, lib=caf.MEASURE_LIB_PATH if any(k.startswith(("CAF_CHAIN", "CAF_R32")) for k in os.environ) else None)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 fr = np.linspace(-100.0, 100.0, F, endpoint=False)
 cdt, tdt = (np.complex128, torch.float64) if dtype == "c128" else (np.complex64, torch.float32)
