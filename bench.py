@@ -392,6 +392,9 @@ def stream_run(plan, nd, hs, lags, total, nslots, batch, split, three_kernels=Fa
             dt = time.perf_counter() - t0
             best = dt if best is None or rep == 1 else min(best, dt)
         ok = int(np.sum(peaks["idx"] == want))
+        hs_ = st.run_stats()  # host-thread time of the LAST pass, per surface
+        stream_run.last_host_us = {k.replace("_s", "_us_per_surface"): v / total * 1e6 for k, v in hs_.items()}
+        stream_run.last_host_us["wall_us_per_surface_last_pass"] = dt / total * 1e6
         st.close()
         return total / best, best / total * 1e6, f"{ok}/{total}"
     bufs = [st.buffers(s) for s in range(nslots)]
@@ -447,6 +450,8 @@ def stream_case(eng, torch, freqs, total=1000):
             ("single_2slots_python_loop", 2, 1, False, False, False)):
         v, us, okc = stream_run(plan, nd, hs, lags, total, nslots, batch, split, three, native)
         forms[name] = {"value": v, "us_per_surface": us, "tau_correct": okc}
+        if native:
+            forms[name]["host_thread"] = dict(getattr(stream_run, "last_host_us", {}))
     plan.close()
     abytes = algorithmic_bytes(1, 400, N_SAMP, "c128")
     best = "single_4slots"

@@ -89,6 +89,7 @@ SYMBOLS = [
     ("caf_stream_destroy", _int, [_vp]),
     ("caf_stream_host_buffers", _int, [_vp, _int, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     ("caf_stream_run", _int, [_vp, _vp, _vp, _sz, _pp, _up, _vp]),
+    ("caf_stream_run_stats", _int, [_vp, _dp]),
     ("caf_stream_submit", _int, [_vp, _int]),
     ("caf_stream_wait", _int, [_vp, _int, _pp, _up, _vp]),
     ("caf_stream_surface", _vp, [_vp, _int]),

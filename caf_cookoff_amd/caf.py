@@ -385,6 +385,12 @@ class Stream:
             ctypes.c_void_p(rval.ctypes.data) if want_rows else None))
         return peaks, ridx, rval
 
+    def run_stats(self) -> dict:
+        """Host-thread seconds of the last :meth:`run`: fill (memcpy into the pinned slots), launch, wait, collect."""
+        a = (ctypes.c_double * 4)()
+        self.plan.eng._check(self.plan.eng.lib.caf_stream_run_stats(self._h, a))
+        return {"fill_s": a[0], "launch_s": a[1], "wait_s": a[2], "collect_s": a[3]}
+
     def surface_ptr(self, slot: int) -> int:
         return int(self.plan.eng.lib.caf_stream_surface(self._h, int(slot)) or 0)
 

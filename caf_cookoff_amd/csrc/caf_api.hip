@@ -1771,6 +1771,7 @@ struct StreamSlot {
 struct caf_stream {
     caf_plan *plan = nullptr;
     size_t batch = 0;
+    double run_stats[4] = {0, 0, 0, 0};  // last caf_stream_run: seconds in {fill (memcpy into pinned), launch, wait (poll / sync), collect}
     bool counted = false;  // registered in plan->live_streams
     std::vector<StreamSlot> slots;
 };
@@ -2162,21 +2163,29 @@ static int stream_run_strided(caf_stream *st, const void *needles, const void *h
     const size_t in1 = p->n * elem_size(p->dtype), rsz = real_size(p->dtype);
     const size_t nsteps = (items + batch - 1) / batch;
     HIPCHK(hipSetDevice(p->ctx->device));
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    double t_fill = 0, t_launch = 0, t_wait = 0, t_collect = 0;
     for (size_t step = 0; step < nsteps + nslots; ++step) {
         StreamSlot &s = st->slots[step % nslots];
         if (step >= nslots && step - nslots < nsteps) {  // collect what this slot carried nslots steps ago
             const size_t j0 = (step - nslots) * batch, k = items - j0 < batch ? items - j0 : batch;
+            const auto w0 = clk::now();
             int rc = caf_stream_wait(st, (int)(step % nslots), nullptr, nullptr, nullptr);
             if (rc) return rc;
+            const auto w1 = clk::now();
+            t_wait += secs(w0, w1);
             for (size_t j = 0; j < k; ++j) {
                 const size_t g = first0 + (j0 + j) * stride;
                 memcpy(peaks + g, (const caf_peak *)s.h_peak + j, sizeof(caf_peak));
                 if (row_idx && rows) memcpy(row_idx + g * rows, (const uint64_t *)s.h_ridx + j * rows, rows * sizeof(uint64_t));
                 if (row_val && rows) memcpy((char *)row_val + g * rows * rsz, (const char *)s.h_rval + j * rows * rsz, rows * rsz);
             }
+            t_collect += secs(w1, clk::now());
         }
         if (step < nsteps) {
             const size_t j0 = step * batch, k = items - j0 < batch ? items - j0 : batch;
+            const auto f0 = clk::now();
             for (size_t j = 0; j < k; ++j) {
                 const size_t g = first0 + (j0 + j) * stride;
                 memcpy((char *)s.h_needle + j * in1, (const char *)needles + g * in1, in1);
@@ -2186,10 +2195,21 @@ static int stream_run_strided(caf_stream *st, const void *needles, const void *h
                 memset((char *)s.h_needle + k * in1, 0, (batch - k) * in1);
                 memset((char *)s.h_hay + k * in1, 0, (batch - k) * in1);
             }
+            const auto f1 = clk::now();
             HIPCHK(hipGraphLaunch(s.exec, s.stream));
             ++s.submits;
+            t_fill += secs(f0, f1);
+            t_launch += secs(f1, clk::now());
         }
     }
+    st->run_stats[0] = t_fill; st->run_stats[1] = t_launch; st->run_stats[2] = t_wait; st->run_stats[3] = t_collect;
+    return CAF_OK;
+}
+
+extern "C" int caf_stream_run_stats(caf_stream *st, double *seconds4)
+{
+    if (!st || !seconds4) return fail(CAF_ERR_BAD_ARG, "caf_stream_run_stats: NULL argument");
+    for (int i = 0; i < 4; ++i) seconds4[i] = st->run_stats[i];
     return CAF_OK;
 }
 

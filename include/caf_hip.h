@@ -247,6 +247,10 @@ int caf_stream_host_buffers(caf_stream *st, int slot, void **needle, void **hays
  * benches call caf_surface once per iteration from Rust, caf_bench.rs:150-168). */
 int caf_stream_run(caf_stream *st, const void *needles, const void *haystacks, size_t count, caf_peak *peaks,
                    uint64_t *row_idx, void *row_val);
+/* Where the host thread spent the last caf_stream_run: seconds4 = {filling the pinned slots (memcpy of the pairs),
+ * launching the graphs, waiting for slots (polled sequence word / stream), collecting results}; the rest of the
+ * call's wall time is loop overhead.  The GPU works under all four. */
+int caf_stream_run_stats(caf_stream *st, double *seconds4);
 /* Replay the slot's graph on the slot's stream (asynchronous). */
 int caf_stream_submit(caf_stream *st, int slot);
 /* Block until the slot's last submit finished; copies out `batch` caf_peak records and,
