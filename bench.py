@@ -63,7 +63,7 @@ HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: ~0.75 s of GPU time at N = 1)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="surfaces per GPU per step (256 x 400 rows = 200 rows "
                     "per resident workgroup on 256 CUs x 2; 64 -> 61.1 k, 128 -> 65.2 k, 256 -> 66.8 k, 512 -> 67.4 k, "
@@ -82,6 +82,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-ceiling", action="store_true", help="skip the live FP64-VALU ceiling measurement")
     ap.add_argument("--peak-reduce", choices=["allreduce", "allgather"], default="allreduce",
                     help="N>1: RCCL all-reduce(max) + all-reduce(min key) (BASELINE north_star), or one all_gather")
+    ap.add_argument("--overlap-peak-exchange", action="store_true",
+                    help="N>1: run step k's peak exchange on a side stream under step k+1's kernels (alternating caf_peak "
+                         "buffers): ~2 %% more surfaces/s with ONE rank under RCCL, but no multi-GPU box has run it yet, so the "
+                         "default keeps the exchange on the main stream")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no GPU work: launch + rendezvous + peak reduction + JSON relay on fabricated shard peaks "
                          "(gloo); what the CPU test suite runs")
@@ -697,13 +701,15 @@ def main():
     case = Case(eng, torch, dev, n_samp, freqs, args.dtype, nsurf, lo, hi)
     plan = case.plan
 
-    # find_peak across the row shards (dist.reduce_global_peak: one RCCL all_gather of 16 B per surface and
-    # rank + a local reduction), OVERLAPPED with the next step's kernels: it runs on a side stream behind an
-    # event recorded after this step's find_peak kernel, on alternating caf_peak buffers; the main stream
-    # waits for a buffer's previous exchange before the kernels write it again.  (On the main stream the
-    # exchange is ~0.1 ms of a 3.9 ms step during which the chip idles: 63.7 k vs 65.5 k surfaces/s.)
+    # find_peak across the row shards (dist.reduce_global_peak with --peak-reduce: RCCL all-reduce(max) + all-reduce(min
+    # key), the form BASELINE's north_star names, or one all_gather of 16 B per surface and rank + a local reduction).
+    # Default: on the main stream, behind the step's find_peak kernel (~0.1 ms of a 3.9 ms step during which the chip
+    # idles: 63.7 k vs 65.5 k surfaces/s with one rank).  --overlap-peak-exchange: on a side stream behind an event
+    # recorded after this step's find_peak kernel, on alternating caf_peak buffers; the main stream waits for a
+    # buffer's previous exchange before the kernels write it again.
+    overlap = coll and not rehearse and args.overlap_peak_exchange
     peaks = [case.peak, torch.empty_like(case.peak)] if coll else [case.peak]
-    side = torch.cuda.Stream(device=dev) if coll and not rehearse else None
+    side = torch.cuda.Stream(device=dev) if overlap else None
     ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
     ev_done = [torch.cuda.Event(), torch.cuda.Event()]
     used = [False, False]
@@ -721,6 +727,10 @@ def main():
             pk_c = pk.cpu()
             pk_ci = pk_c.view(torch.int64)
             return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2], method=args.peak_reduce, always_collective=True)
+        if not overlap:
+            case.launch(peak=pk)
+            pki = pk.view(torch.int64)
+            return reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=args.peak_reduce, always_collective=True)
         main = torch.cuda.current_stream()
         if used[k]:
             main.wait_event(ev_done[k])
@@ -805,6 +815,8 @@ def main():
                                    f"filterbank CAF (BASELINE configs[{cfg_idx}]), n={n_samp}, fs=48000",
                        "surfaces_per_step": nsurf, "batch_per_gpu": args.batch,
                        "rows_per_gpu": rows, "parallelism": f"doppler-row-shard x{world}" if world > 1 else "single",
+                       "peak_exchange": (f"{args.peak_reduce}, {'overlapped on a side stream' if overlap else 'on the main stream'}"
+                                         if coll else None),
                        "kernel_path": plan.path, "device": devname, "cus": cu,
                        "devices_visible_per_rank": ndev, "kernel_source_hash": kernel_source_hash(plan.kernel_name)},
             "roofline": roof,

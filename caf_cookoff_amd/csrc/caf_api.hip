@@ -30,11 +30,11 @@
 // the environment switches that select them.  The product library contains none of it and reads
 // no environment variable.
 #ifdef CAF_MEASURE
-#include "kernels_r8_4096.hpp"
-#include "kernels_big65536.hpp"  // four-step tiled n = 32768 path of round 1 (CAF_CHAIN=0), superseded by the chain path
-#include "kernels_q65536.hpp"
-#include "kernels_ablate.hpp"     // arithmetic-only memory policies (issue ceilings; wrong results)
-#include "kernels_r32.hpp"        // configs[3] with 32 points per thread (CAF_R32=1): VERDICT r02 item 4, measured and rejected or promoted
+#include "measure/kernels_r8_4096.hpp"
+#include "measure/kernels_big65536.hpp"  // four-step tiled n = 32768 path of round 1 (CAF_CHAIN=0), superseded by the chain path
+#include "measure/kernels_q65536.hpp"
+#include "measure/kernels_ablate.hpp"     // arithmetic-only memory policies (issue ceilings; wrong results)
+#include "measure/kernels_r32.hpp"        // configs[3] with 32 points per thread (CAF_R32=1): VERDICT r02 item 4, measured and rejected or promoted
 #endif
 
 using namespace caf;

@@ -69,7 +69,7 @@ struct DuoIo {
     }
     // every other access to memory the row makes goes through these hooks too, so that the measurement
     // library can instantiate the SAME kernel body with a policy that keeps everything in registers
-    // (kernels_ablate.hpp, DuoIoNull: the packed-f32 / FP64 issue ceiling bench.py reports); the product
+    // (measure/kernels_ablate.hpp, DuoIoNull: the packed-f32 / FP64 issue ceiling bench.py reports); the product
     // library only ever instantiates this policy
     __device__ __forceinline__ void sink_A(int k, cpx<T> x) const { Lc[L.pA + k * F_BLK] = x; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }

@@ -3,7 +3,7 @@
 // object its memory hooks go through differs.  Results are WRONG by construction -- timing only: what remains is
 // the VALU instruction stream of the row, i.e. the issue ceiling bench.py reports as `secondary`.
 #pragma once
-#include "kernels_duo4096.hpp"
+#include "../kernels_duo4096.hpp"
 
 namespace caf {
 

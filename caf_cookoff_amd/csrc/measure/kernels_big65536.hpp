@@ -24,7 +24,7 @@
 // HBM traffic per row (c64): 512 KiB written + 512 KiB read/written + 512 KiB read
 // + 256 KiB surface = 9x the algorithmic 256 KiB -- the price of L > LDS.
 #pragma once
-#include "kernels_fused4096.hpp"
+#include "../kernels_fused4096.hpp"
 
 namespace caf {
 

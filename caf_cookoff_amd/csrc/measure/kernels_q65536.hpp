@@ -29,7 +29,7 @@
 // 4096 x 65536 surface, so the three-pass form stays the product path.
 #pragma once
 #include "kernels_big65536.hpp"
-#include "kernels_duo4096.hpp"
+#include "../kernels_duo4096.hpp"
 
 namespace caf {
 

@@ -22,7 +22,7 @@
 // pattern B = 560 g + o + 17 j, pattern C = 560 g + 17 k' + o'.  560 = 512 + 32 pads + 16: 560 mod 32 = 16
 // puts the two blocks a half-wave touches in patterns B and C on disjoint bank halves.
 #pragma once
-#include "kernels_chain.hpp"
+#include "../kernels_chain.hpp"
 
 namespace caf {
 

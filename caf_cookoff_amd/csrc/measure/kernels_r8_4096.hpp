@@ -27,7 +27,7 @@
 // one extra complex multiply each), W_512^(l*k) and W_64^((l&7)*k) from LDS tables.
 // LDS per workgroup: 4608*16 + 7*64*16 + 7*8*16 + 128 = 81 920 B = exactly half a CU's 160 KiB.
 #pragma once
-#include "kernels_fused4096.hpp"
+#include "../kernels_fused4096.hpp"
 
 namespace caf {
 

@@ -396,3 +396,23 @@ def test_r32_variant_matches_oracle_and_product_kernel(eng, oracle, monkeypatch)
     part = np.partition(surf.astype(np.float64), -2, axis=1)
     clear = (part[:, -1] - part[:, -2]) > 1e-4 * mx
     assert np.array_equal(ridx[clear], ridx0[clear].astype(np.int64)) and (pk["freq"], int(pk["idx"])) == (pk0.freq, pk0.idx) == (-31.5, lag)
+
+
+def test_stream_run_stats_account_for_the_host_thread(eng):
+    """caf_stream_run_stats: where the host thread spent the last caf_stream_run (fill / launch / wait / collect);
+    the four parts are non-negative and add up to no more than the call's wall time."""
+    import time
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.synth import make_batch
+    nd, hs, lags, _ = make_batch(32, 4096, FS, seed0=4100)
+    plan = eng.plan(4096, caf.bench_shifts(), FS)
+    st = caf.Stream(plan, batch=1, nslots=3, want_surface=False)
+    st.run(nd[:4], hs[:4])
+    t0 = time.perf_counter()
+    peaks, _, _ = st.run(nd, hs)
+    wall = time.perf_counter() - t0
+    s = st.run_stats()
+    assert all(v >= 0.0 for v in s.values()) and 0.0 < sum(s.values()) <= wall
+    assert [int(p["idx"]) for p in peaks] == list(lags)
+    st.close()
+    plan.close()
