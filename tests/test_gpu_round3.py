@@ -416,3 +416,13 @@ def test_stream_run_stats_account_for_the_host_thread(eng):
     assert [int(p["idx"]) for p in peaks] == list(lags)
     st.close()
     plan.close()
+
+
+def test_short_host_api_soak():
+    """tools/host_api_soak.py, short form: 4000 polled host-pointer calls per dtype, every result bit-equal to round 0."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("host_api_soak", ROOT / "tools" / "host_api_soak.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(4000, "c128", log=False) == 0
+    assert mod.run(4000, "c64", log=False) == 0
