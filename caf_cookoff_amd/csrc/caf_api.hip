@@ -736,7 +736,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
     if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";  // measurement build
     if (p->big) return f64 ? "caf::k_big_rows<double>" : "caf::k_big_rows<float>";  // measurement build
     if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
-    if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 0, 0, 15>" : "caf::k_seq_rows<float, 0, 0, 15>";
+    if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 15, caf::SeqIo<double> >" : "caf::k_seq_rows<float, 15, caf::SeqIo<float> >";
     if (p->variant == 2) return f64 ? "caf::k_r8_rows<double, 0>" : "caf::k_r8_rows<float, 0>";
     if (p->variant == 3) return f64 ? "caf::k_duo_rows<double, 0, caf::DuoIo<double> >" : "caf::k_duo_rows<float, 0, caf::DuoIo<float> >";
     return f64 ? "caf::k_fused_rows<double, false>" : "caf::k_fused_rows<float, false>";
@@ -782,18 +782,16 @@ extern "C" int caf_plan_timing_end(caf_plan *p, double *ms_total, uint64_t *laun
 
 #ifdef CAF_MEASURE
 // Measurement build only (not in include/caf_hip.h): route the next caf_surface_dev calls of an
-// n = 4096 plan through a stamped DIAG instantiation.  d_buf = `len_u64` device u64 words or NULL to
-// stop.  Variant 0 (k_seq_rows<T,0,8,15>) writes 32*4*S_NSTAMP stamp words plus 4 words per
-// workgroup of the launch; variant 1 (k_fused_rows<T,true>) writes 32*8*F_NSTAMP words.  The other
-// variants have no DIAG build.
+// n = 4096 plan through the stamped DIAG instantiation of the lane-half kernel (CAF_ROW_KERNEL=1,
+// k_fused_rows<T,true>: 32*8*F_NSTAMP words).  d_buf = `len_u64` device u64 words or NULL to stop.  The other
+// variants have no DIAG build (the stamped form of k_seq_rows went with round 3's clean-up of that kernel).
 extern "C" int caf_debug_set_stamps(caf_plan *p, void *d_buf, size_t len_u64)
 {
     if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
     if (d_buf) {
-        if (!p->fused || (p->variant != 0 && p->variant != 1))
+        if (!p->fused || p->variant != 1)
             return fail(CAF_ERR_BAD_ARG, "caf_debug_set_stamps: row kernel variant %d has no stamped build", p->variant);
-        const size_t max_grid = (size_t)p->ctx->cu_count * 8;
-        const size_t need = p->variant == 0 ? (size_t)32 * 4 * S_NSTAMP + 4 * max_grid : (size_t)32 * 8 * F_NSTAMP;
+        const size_t need = (size_t)32 * 8 * F_NSTAMP;
         if (len_u64 < need)
             return fail(CAF_ERR_BAD_ARG, "caf_debug_set_stamps: buffer of %zu u64 words, %zu needed", len_u64, need);
     }
@@ -880,25 +878,15 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
         k_duo_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
     } else if (p->variant == 3 && store_mode == 33) {  // VALU only: the product body over the null memory policy
         k_duo_rows<T, 0, DuoIoNull<T>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
-    } else if (p->variant == 0 && p->dbg) {
-        k_seq_rows<T, 0, 8, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
     } else if (p->variant == 0 && store_mode != 0) {
-        switch (store_mode) {  // measurement variants; 3, 5, 11-13, 31-35 produce WRONG results (timing only)
-        case 1: k_seq_rows<T, 1><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
-        case 2: k_seq_rows<T, 2><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
-        case 3: k_seq_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
-        case 5: k_seq_rows<T, 5><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
-        case 4: k_seq_rows<T, 4><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;
-        case 11: k_seq_rows<T, 0, 1, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS
-        case 12: k_seq_rows<T, 0, 2, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no global loads
-        case 13: k_seq_rows<T, 3, 3, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // VALU only
-        case 20: k_seq_rows<T, 0, 0, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;   // no software pipelining
-        case 31: k_seq_rows<T, 0, 1, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS, pipelined loads
-        case 32: k_seq_rows<T, 0, 2, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no global loads
-        case 33: k_seq_rows<T, 3, 3, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // VALU only
-        case 34: k_seq_rows<T, 3, 1, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS, no stores
-        case 35: k_seq_rows<T, 3, 2, 15><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no loads, no stores
-        case 21: k_seq_rows<T, 0, 0, 31><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // deferred argmax publish
+        switch (store_mode) {  // measurement policies over the product kernel body (WRONG results, timing only), and PF = 0
+        case 3: k_seq_rows<T, 15, SeqIoCut<T, 4>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;   // no surface stores
+        case 31: k_seq_rows<T, 15, SeqIoCut<T, 1>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS traffic / barriers
+        case 32: k_seq_rows<T, 15, SeqIoCut<T, 2>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no global loads
+        case 33: k_seq_rows<T, 15, SeqIoCut<T, 7>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // VALU only
+        case 34: k_seq_rows<T, 15, SeqIoCut<T, 5>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS, no stores
+        case 35: k_seq_rows<T, 15, SeqIoCut<T, 6>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no loads, no stores
+        case 20: k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;                    // no software pipelining (correct results)
         default: return fail(CAF_ERR_BAD_ARG, "CAF_STORE_MODE=%d: no such measurement mode", store_mode);
         }
     } else
@@ -906,7 +894,7 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     if (p->variant == 3)
         k_duo_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex64 product kernel
     else
-        k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex128 product kernel
+        k_seq_rows<T><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex128 product kernel
     KCHK();
     if ((rc = timing_mark(p))) return rc;
     return CAF_OK;

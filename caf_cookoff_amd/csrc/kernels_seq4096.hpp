@@ -48,21 +48,18 @@ struct SeqLane {
 
 // One chain of one row: needle samples -> y[m2] = IDFT_4096(C_chain)[t + 256*m2].
 // 2 workgroup barriers; exchanges 2 and 3 are wave-local.
-// ABL (measurement builds only, wrong results): bit0 = no LDS traffic/barriers (values stay
-// in registers), bit1 = no global loads (operands synthesised), bit2 = no butterfly math.
 template <typename T>
 __device__ __forceinline__ void keep(cpx<T> &x)
 {
     asm volatile("" : "+v"(x.x), "+v"(x.y));
 }
 
-// PF (software pipelining of the input loads; each bit moves one group of loads earlier):
+// PF (software pipelining of the input loads; each bit moves one group of loads earlier; the product rows run
+// PF = 15, the one-launch surface kernel 14):
 //   1: even chain - haystack-spectrum loads issued right after the mixer
 //   2: odd chain  - needle samples loaded during the even chain's last pass
 //   4: odd chain  - haystack-spectrum loads issued before pass 3
 //   8: even chain - the NEXT row's needle samples loaded while the epilogue retires registers
-//  16: (not a load) publish a row's argmax after the next row's first barriers instead of
-//      behind a barrier of its own
 template <typename T>
 __device__ __forceinline__ void load_samples(cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t rs_sig, const SeqLane &L)
 {
@@ -72,27 +69,65 @@ __device__ __forceinline__ void load_samples(cpx<T> (&a)[16], const __amdgpu_buf
         a[q] = bload(rs_sig, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * q * sizeof(C)), (C *)nullptr);
 }
 
-// ABL bit 3: s_memtime stamps (diagnostic build, tools/stamps_seq.py)
-constexpr int S_NSTAMP = 28;
-#define SEQ_STAMP(i)                                                                             \
-    if constexpr (ABL & 8) {                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[(i) + CH * 11])::"memory"); \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
+// MEMORY POLICY of the sequential-chain kernels: every LDS access, barrier, global load and surface store a row makes
+// goes through these hooks.  The product instantiates SeqIo<T> and nothing else; the measurement library instantiates
+// the SAME kernel bodies over policies that leave some of the accesses out (measure/kernels_ablate.hpp: VALU only,
+// no LDS, no loads, no stores -- wrong results, timing only) for the issue ceiling bench.py reports.
+template <typename T>
+struct SeqIo {
+    using C = cpx<T>;
+    C *Lc;           // the workgroup's padded chain
+    const C *twB;    // LDS table W_256^(lo4 k) at [16 k]
+    const SeqLane &L;
+    // exchange patterns (kernels_fused4096.hpp, "LDS geometry"): A by column, B gather, C transposed
+    __device__ __forceinline__ void sinkA(int k, C x) const { Lc[L.pA + k * F_BLK] = x; }
+    __device__ __forceinline__ void sinkB(int k, C x) const { Lc[L.pB + 17 * k] = x; }
+    __device__ __forceinline__ void sinkC(int k, C x) const { Lc[L.pC + k] = x; }
+    __device__ __forceinline__ void readA(C (&v)[16]) const
+    {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pA + k * F_BLK];
     }
+    __device__ __forceinline__ void readB(C (&v)[16]) const
+    {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
+    }
+    __device__ __forceinline__ void readC(C (&v)[16]) const
+    {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pC + k];
+    }
+    __device__ __forceinline__ C twb(int k) const { return twB[16 * k]; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ void fence() const { wave_lds_fence(); }
+    // global memory: needle samples, haystack-spectrum values, surface stores
+    __device__ __forceinline__ void samples(C (&a)[16], const __amdgpu_buffer_rsrc_t rs_sig) const { load_samples(a, rs_sig, L); }
+    __device__ __forceinline__ C sample(const __amdgpu_buffer_rsrc_t rs_sig, int i) const
+    {
+        return bload(rs_sig, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * i * sizeof(C)), (C *)nullptr);
+    }
+    __device__ __forceinline__ C spec(const __amdgpu_buffer_rsrc_t rs_spec, unsigned voff, int k) const
+    {
+        return bload(rs_spec, voff, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
+    }
+    template <typename V>
+    __device__ __forceinline__ void store(const __amdgpu_buffer_rsrc_t rs, unsigned byte_off, V d) const
+    {
+        store_vec_aux<CAF_AUX_SC1>(rs, byte_off, d);  // 16-byte write-through
+    }
+};
 
 // HW: called once before the haystack-spectrum values are requested (k_seq_surface waits there for the
 // workgroups that compute them; a no-op everywhere else)
 struct SeqNoWait {
     __device__ __forceinline__ void operator()() const {}
 };
-template <typename T, int CH, int ABL = 0, int PF = 0, typename HW = SeqNoWait>
-__device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t rs_sig,
+template <typename T, int CH, int PF, typename IO, typename HW = SeqNoWait>
+__device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], const IO &io, const __amdgpu_buffer_rsrc_t rs_sig,
                                           const __amdgpu_buffer_rsrc_t rs_spec, const cpx<T> pb, const cpx<T> post,
-                                          const cpx<T> *__restrict__ ps, const TwSet<T> &tw, const cpx<T> *twB,
-                                          cpx<T> *Lc, const SeqLane &L, unsigned long long (&st)[S_NSTAMP], HW hwait = HW{})
+                                          const cpx<T> *__restrict__ ps, const TwSet<T> &tw, const SeqLane &L, HW hwait = HW{})
 {
-    SEQ_STAMP(0);
     using C = cpx<T>;
     const unsigned voff_spec = (unsigned)((CH * 4096 + L.t) * sizeof(C));
     constexpr bool A_PRELOADED = (CH == 0 && (PF & 8)) || (CH == 1 && (PF & 2));
@@ -100,93 +135,55 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
     constexpr bool H_MID = (CH == 1 && (PF & 4));
     C h[16];
     // ---- mixer (mod.rs:46-65) fused into the first butterfly's operands -----------------
-    {
+    if constexpr (!A_PRELOADED) io.samples(a, rs_sig);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            if constexpr (ABL & 2) { a[q] = C{T(q + 1), T(L.t)}; keep(a[q]); }
-        }
-        if constexpr (!(ABL & 2) && !A_PRELOADED) load_samples(a, rs_sig, L);
-#pragma unroll
-        // conj(a * w^t * step[q]) = conj(a * step[q]) * conj(w^t): the lane factor conj(w^t)
-        // commutes with the first butterfly and is folded into its output twiddles (TwFold)
-        for (int q = 0; q < 16; ++q) v[q] = cmul_conj(a[q], ps[q]);
-    }
+    // conj(a * w^t * step[q]) = conj(a * step[q]) * conj(w^t): the lane factor conj(w^t)
+    // commutes with the first butterfly and is folded into its output twiddles (TwFold)
+    for (int q = 0; q < 16; ++q) v[q] = cmul_conj(a[q], ps[q]);
     const TwFold<T> fmix(tw, conj(pb));
     if constexpr (H_EARLY) {
         hwait();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
+        for (int k = 0; k < 16; ++k) h[k] = io.spec(rs_spec, voff_spec, k);
     }
-    SEQ_STAMP(1);  // mixer done
     // ---- forward (DIF) ------------------------------------------------------------------
-    if constexpr (ABL & 1) {
-        dft16(v);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { v[k] = twA_k(v[k], k, tw, fmix); keep(v[k]); }
-        dft16(v);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) { v[k] = cmul(v[k], tw.w3); keep(v[k]); }
-    } else {
-        dft16_sink(v, [&](int k, C x) { Lc[L.pA + k * F_BLK] = twA_k(x, k, tw, fmix); });
-        SEQ_STAMP(2);  // DFT#1 + twA + ex1 writes retired
-        __syncthreads();
-        SEQ_STAMP(3);  // barrier ex1
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
-        dft16_sink(v, [&](int k, C x) { Lc[L.pB + 17 * k] = k ? cmul(x, twB[16 * k]) : x; });
-        SEQ_STAMP(4);  // ex1 read + DFT#2 + twB + ex2 writes
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pC + k];
-    }
+    dft16_sink(v, [&](int k, C x) { io.sinkA(k, twA_k(x, k, tw, fmix)); });
+    io.sync();
+    io.readB(v);
+    dft16_sink(v, [&](int k, C x) { io.sinkB(k, k ? cmul(x, io.twb(k)) : x); });
+    io.fence();
+    io.readC(v);
     if constexpr (H_MID) {
         hwait();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) h[k] = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
+        for (int k = 0; k < 16; ++k) h[k] = io.spec(rs_spec, voff_spec, k);
     }
     dft16(v);
-    SEQ_STAMP(5);  // ex2 read + DFT#3
     if constexpr (!(H_EARLY || H_MID)) hwait();
     // ---- spectrum product (xcor_rustfft.rs:64-73) ------------------------------------------
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         C hk;
-        if constexpr (ABL & 2) { hk = C{T(1), T(k)}; keep(hk); }
-        else if constexpr (H_EARLY || H_MID) hk = h[k];
-        else hk = bload(rs_spec, voff_spec, (unsigned)(256 * k * sizeof(C)), (C *)nullptr);
+        if constexpr (H_EARLY || H_MID) hk = h[k];
+        else hk = io.spec(rs_spec, voff_spec, k);
         v[k] = cmul(v[k], hk);
     }
     // ---- inverse (DIT) ----------------------------------------------------------------------
-    if constexpr (ABL & 1) {
-        dft16(v);
+    io.fence();
+    dft16_sink(v, [&](int k, C x) { io.sinkC(k, x); });
+    io.fence();
+    io.readB(v);
 #pragma unroll
-        for (int k = 1; k < 16; ++k) { v[k] = cmul(v[k], tw.w2); keep(v[k]); }
-        dft16(v);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) keep(v[k]);
-    } else {
-        wave_lds_fence();
-        dft16_sink(v, [&](int k, C x) { Lc[L.pC + k] = x; });
-        SEQ_STAMP(6);  // H mul + DFT#4 + ex3 writes
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pB + 17 * k];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twB[16 * k]);
-        wave_lds_fence();
-        dft16_sink(v, [&](int k, C x) { Lc[L.pB + 17 * k] = x; });
-        SEQ_STAMP(7);  // ex3 read + twB + DFT#5 + ex4 writes
-        __syncthreads();
-        SEQ_STAMP(8);  // barrier ex4
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = Lc[L.pA + k * F_BLK];
-        // No barrier here: the next exchange-1 write (pattern A) of this thread overwrites exactly
-        // the sixteen addresses it has just read, and nobody else touches them before the barrier
-        // that follows that write.
-        SEQ_STAMP(9);  // ex4 read
-    }
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], io.twb(k));
+    io.fence();
+    dft16_sink(v, [&](int k, C x) { io.sinkB(k, x); });
+    io.sync();
+    io.readA(v);
+    // No barrier here: the next exchange-1 write (pattern A) of this thread overwrites exactly
+    // the sixteen addresses it has just read, and nobody else touches them before the barrier
+    // that follows that write.
     // the odd chain reads the same needle samples: fetch them under the last butterfly
-    if constexpr (CH == 0 && (PF & 2) && !(ABL & 2)) load_samples(a, rs_sig, L);
+    if constexpr (CH == 0 && (PF & 2)) io.samples(a, rs_sig);
     if constexpr (CH == 1) {  // odd chain: T^t of the last radix-2 stage folded into the twiddles
         const TwFold<T> fpost(tw, post);
 #pragma unroll
@@ -195,7 +192,6 @@ __device__ __forceinline__ void seq_chain(cpx<T> (&v)[16], cpx<T> (&a)[16], cons
         apply_twA(v, tw);
     }
     dft16(v);
-    SEQ_STAMP(10);  // twA + DFT#6
 }
 
 // ---- haystack spectrum, one 256-thread workgroup per (surface, chain) ------------------------
@@ -287,8 +283,6 @@ __device__ __forceinline__ void axpy_w32(int i, cpx<T> e, cpx<T> z, cpx<T> &lo, 
     bfly_w(e, z, W32C16[i], W32S16[i], lo, hi);
 }
 
-// STORE: 0 = 16-B write-through (sc1), 1 = 16-B plain, 2 = 16-B nontemporal, 3 = no surface store
-// (1-3 are measurement variants, selected with CAF_STORE_MODE; the product launches 0).
 // waves per SIMD the register allocator must leave room for: f64 rows need 256 VGPRs (2; LDS
 // allows no more anyway); the packed-f32 rows fit 168 without spills (3 workgroups of 36 KiB LDS
 // per CU: 108.6 k surfaces/s vs 103.5 k at 2 x 216 VGPRs and 102.8 k at 4 x 128 with 31 spills)
@@ -298,7 +292,8 @@ constexpr int seq_waves_per_simd() { return sizeof(T) == 8 ? 2 : 3; }
 // `phasor` is passed as its own __restrict__ parameter (not inside FusedArgs) so that the
 // wave-uniform step entries become scalar loads: they cost no vector-memory issue slot and,
 // unlike vector loads, are not ordered behind the epilogue's stores by the in-order vmcnt.
-template <typename T, int STORE = 0, int ABL = 0, int PF = 15>
+// IO: the memory policy (SeqIo<T> in the product; see there).
+template <typename T, int PF = 15, typename IO = SeqIo<T>>
 __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows(const FusedArgs<T> A,
                                                                              const cpx<T> *__restrict__ phasor)
 {
@@ -317,7 +312,7 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
     tw.w8 = A.tab.tw4096[L.t * 8];
     tw.w12 = A.tab.tw4096[L.t * 12];
     twb[L.tid] = A.tab.tw4096[16 * (L.tid & 15) * (L.tid >> 4)];
-    const C *const twB = twb + L.lo4;
+    const IO io{Lc, twb + L.lo4, L};
     const C th = A.tab.th[L.t];       // T^t = e^{2*pi*i*t/8192}
     const C cfac = conj(th);          // odd chain input rotation e^{-2*pi*i*t/8192}
     const int mpair = L.t & ~1;
@@ -325,15 +320,11 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
     constexpr unsigned long long EVEN_LANES = 0x5555555555555555ull;
     __syncthreads();
 
-    unsigned long long st[S_NSTAMP] = {};
-    int iter = 0;
-    unsigned long long wg_t0 = 0;
-    if constexpr (ABL & 8) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0)::"memory");
     C a[16];
     if constexpr (PF & 8) {
         const int gc = (int)blockIdx.x < A.total ? (int)blockIdx.x : A.total - 1;
-        load_samples(a, __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0,
-                                                          F_N * (int)sizeof(C), 0x00020000), L);
+        io.samples(a, __builtin_amdgcn_make_buffer_rsrc((void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0,
+                                                        F_N * (int)sizeof(C), 0x00020000));
     }
     // Rows are handed out dynamically: workgroup i starts with row i, then draws tickets
     // gridDim + 0, 1, 2 ... from one device-scope counter (zeroed by the prepare kernel that
@@ -349,20 +340,6 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
         const C *ph0 = phasor + (size_t)(g0 % A.rows) * 64;
         pb = cmul(ph0[L.lo4], ph0[16 + L.hi4]);
     }
-    int prev_g = -1, parity = 0;
-    // Per-wave argmax partials go to scratch slot `parity`; they are merged into the row's result
-    // after the NEXT row's first two barriers (or after the loop), so a row needs no barrier of
-    // its own for that.
-    auto publish = [&](int row, int slot) {
-        const T *sv = reinterpret_cast<const T *>(scratch + slot * 64);
-        const uint32_t *si = reinterpret_cast<const uint32_t *>(scratch + slot * 64 + 32);
-        T bv = sv[0];
-        uint32_t bi = si[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) arg_merge(bv, bi, sv[w], si[w]);
-        A.row_idx[row] = bi;
-        A.row_val[row] = bv;
-    };
     for (int g = blockIdx.x; g < A.total;) {
         if (L.tid == 0)
             *next_row = A.work ? (int)gridDim.x + (int)atomicAdd(A.work, 1u) : g + (int)gridDim.x;
@@ -373,22 +350,18 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
         const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.spec + (size_t)b * (2 * 16 * 256)), 0, 2 * 16 * 256 * (int)sizeof(C), 0x00020000);
         C e[16], o[16];
-        seq_chain<T, 0, ABL, PF>(e, a, rs_sig, rs_spec, pb, th, ph + 32, tw, twB, Lc, L, st);
+        seq_chain<T, 0, PF>(e, a, io, rs_sig, rs_spec, pb, th, ph + 32, tw, L);
         // the ticket was stored before the chain's barriers: visible to every wave by now
         const int gn = __builtin_amdgcn_readfirstlane(*next_row);
-        if constexpr (PF & 16) {
-            if (L.tid == 0 && prev_g >= 0) publish(prev_g, parity ^ 1);
-        }
         const int gc = gn < A.total ? gn : A.total - 1;  // clamped: a[] is always redefined
         const __amdgpu_buffer_rsrc_t rs_sig_next = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(A.sig + (size_t)(gc / A.rows) * F_N), 0, F_N * (int)sizeof(C), 0x00020000);
-        seq_chain<T, 1, ABL, PF>(o, a, rs_sig, rs_spec, cmul(pb, cfac), th, ph + 48, tw, twB, Lc, L, st);
+        seq_chain<T, 1, PF>(o, a, io, rs_sig, rs_spec, cmul(pb, cfac), th, ph + 48, tw, L);
 
         // ---- last radix-2 stage (in registers) + |.|^2 + argmax + 16-B write-through stores --
         T bv_lo = T(0), bv_hi = T(0);
         int bi_lo = 0, bi_hi = 0;
-        // STORE 5 (measurement, wrong results): every row of a workgroup lands on the same 64 KiB
-        T *const out = A.surface ? A.surface + (size_t)(STORE == 5 ? (int)blockIdx.x : g) * F_L : nullptr;
+        T *const out = A.surface ? A.surface + (size_t)g * F_L : nullptr;
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? F_L * (int)sizeof(T) : 0, 0x00020000);
         // All magnitudes first; each retired (e[i], o[i]) pair frees the registers that receive the
@@ -406,80 +379,38 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_rows
             bv_lo = vmax(bv_lo, mlo[i]);         // one v_max instead of a 64-bit select
             bi_hi = mhi[i] > bv_hi ? i : bi_hi;
             bv_hi = vmax(bv_hi, mhi[i]);
-            if constexpr (PF & 8)
-                a[i] = bload(rs_sig_next, (unsigned)(L.t * sizeof(C)), (unsigned)(256 * i * sizeof(C)), (C *)nullptr);
+            if constexpr (PF & 8) a[i] = io.sample(rs_sig_next, i);
         }
-        if constexpr (ABL & 8) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[23])::"memory"); __builtin_amdgcn_sched_barrier(0); }
         {   // phasor base of the next row
             const C *phn = phasor + (size_t)(gc % A.rows) * 64;
             pb = cmul(phn[L.lo4], phn[16 + L.hi4]);
         }
-        if constexpr (STORE == 4) {  // one element per lane and store: no cross-lane pairing work
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                store_one_aux<CAF_AUX_SC1>(rs, (unsigned)(L.t * sizeof(T)), (unsigned)(256 * i * sizeof(T)), mlo[i]);
-                store_one_aux<CAF_AUX_SC1>(rs, (unsigned)(L.t * sizeof(T)), (unsigned)((256 * i + F_N) * sizeof(T)), mhi[i]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                typename pair_vec<T>::type dlo, dhi;
-                pair_xor1(mlo[2 * j], mlo[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dlo);
-                pair_xor1(mhi[2 * j], mhi[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dhi);
-                const int m = mpair + 256 * (2 * j + (odd ? 1 : 0));
-                if constexpr (STORE != 3) {
-                    constexpr int AUX = (STORE == 0 || STORE == 5) ? CAF_AUX_SC1 : STORE == 2 ? 2 : 0;
-                    store_vec_aux<AUX>(rs, (unsigned)(m * sizeof(T)), dlo);
-                    store_vec_aux<AUX>(rs, (unsigned)((m + F_N) * sizeof(T)), dhi);
-                } else {
-                    asm volatile("" ::"v"(dlo), "v"(dhi));
-                }
-            }
+        for (int j = 0; j < 8; ++j) {
+            typename pair_vec<T>::type dlo, dhi;
+            pair_xor1(mlo[2 * j], mlo[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dlo);
+            pair_xor1(mhi[2 * j], mhi[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dhi);
+            const int m = mpair + 256 * (2 * j + (odd ? 1 : 0));
+            io.store(rs, (unsigned)(m * sizeof(T)), dlo);
+            io.store(rs, (unsigned)((m + F_N) * sizeof(T)), dhi);
         }
-        if constexpr (ABL & 8) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[24])::"memory"); __builtin_amdgcn_sched_barrier(0); }
         T bv = bv_lo;
         uint32_t bi = bv_lo > T(0) ? (uint32_t)(L.t + 256 * bi_lo) : 0u;
         if (bv_hi > bv) { bv = bv_hi; bi = (uint32_t)(L.t + 256 * bi_hi + F_N); }
         wave_arg_reduce_maxmin(bv, bi);
-        {
-            T *sv = reinterpret_cast<T *>(scratch + parity * 64);
-            uint32_t *si = reinterpret_cast<uint32_t *>(scratch + parity * 64 + 32);
-            if (L.lane == 63) { sv[L.wave] = bv; si[L.wave] = bi; }
-        }
-        if constexpr (PF & 16) {
-            prev_g = g;
-            parity ^= 1;
-        } else {  // publish now: one more barrier per row, which also re-aligns the four waves
-            __syncthreads();
-            if (L.tid == 0) publish(g, 0);
-        }
-        if constexpr (ABL & 8) {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[22])::"memory");
-            if (blockIdx.x == 0 && L.lane == 0 && iter < 32) {
+        T *const sv = reinterpret_cast<T *>(scratch);
+        uint32_t *const si = reinterpret_cast<uint32_t *>(scratch + 32);
+        if (L.lane == 63) { sv[L.wave] = bv; si[L.wave] = bi; }
+        __syncthreads();  // the argmax publication: one more barrier per row, which also re-aligns the four waves
+        if (L.tid == 0) {
+            bv = sv[0];
+            bi = si[0];
 #pragma unroll
-                for (int i = 0; i < S_NSTAMP; ++i) A.dbg[((size_t)iter * 4 + L.wave) * S_NSTAMP + i] = st[i];
-            }
-            ++iter;
+            for (int w = 1; w < 4; ++w) arg_merge(bv, bi, sv[w], si[w]);
+            A.row_idx[g] = bi;
+            A.row_val[g] = bv;
         }
         g = gn;
-    }
-    if constexpr (PF & 16) {
-        __syncthreads();  // last row's partials
-        if (L.tid == 0 && prev_g >= 0) publish(prev_g, parity ^ 1);
-    }
-    if constexpr (ABL & 8) {
-        unsigned long long wg_t1;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1)::"memory");
-        if (L.tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
-            unsigned long long *rec = A.dbg + 32 * 4 * S_NSTAMP + (size_t)blockIdx.x * 4;
-            rec[0] = wg_t0;
-            rec[1] = wg_t1;
-            rec[2] = ((unsigned long long)(xcc & 15u) << 32) | hw;
-            rec[3] = (unsigned long long)iter;
-        }
     }
 }
 

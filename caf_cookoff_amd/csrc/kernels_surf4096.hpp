@@ -190,7 +190,6 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_surf
         __builtin_amdgcn_make_buffer_rsrc((void *)A.sig, 0, F_N * (int)sizeof(C), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_spec =
         __builtin_amdgcn_make_buffer_rsrc((void *)A.spec, 0, 2 * 16 * 256 * (int)sizeof(C), 0x00020000);
-    unsigned long long st[S_NSTAMP] = {};
     C a[16];
     load_samples(a, rs_sig, L);
     C e[16], o[16];
@@ -202,12 +201,13 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_seq_surf
     // wave polls for itself (no barrier inside the chain)
     bool okh = true;
     const unsigned h_early = S.prep_blocks ? __hip_atomic_load(&S.sync[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    seq_chain<T, 0, 0, PF>(e, a, rs_sig, rs_spec, pb, th, ph + 32, tw, twB, Lc, L, st, [&]() {
+    const SeqIo<T> io{Lc, twB, L};
+    seq_chain<T, 0, PF>(e, a, io, rs_sig, rs_spec, pb, th, ph + 32, tw, L, [&]() {
         if (__builtin_amdgcn_readfirstlane(h_early) < S.prep_blocks) okh = surf_wait(&S.sync[64], S.prep_blocks);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     });
-    seq_chain<T, 1, 0, PF>(o, a, rs_sig, rs_spec, cmul(pb, cfac), th, ph + 48, tw, twB, Lc, L, st);
+    seq_chain<T, 1, PF>(o, a, io, rs_sig, rs_spec, cmul(pb, cfac), th, ph + 48, tw, L);
 
     // last radix-2 stage + |.|^2 + argmax + 16-byte write-through stores (k_seq_rows epilogue, one row)
     T bv_lo = T(0), bv_hi = T(0);

@@ -1,5 +1,5 @@
 // kernels_ablate.hpp -- MEASUREMENT LIBRARY ONLY (-DCAF_MEASURE): memory policies that turn a product row
-// kernel into its arithmetic-only skeleton.  The kernel body is the product's, unchanged; only the policy
+// kernel (k_duo_rows, k_seq_rows) into its arithmetic-only skeleton, or leave out one kind of memory access.  The kernel body is the product's, unchanged; only the policy
 // object its memory hooks go through differs.  Results are WRONG by construction -- timing only: what remains is
 // the VALU instruction stream of the row, i.e. the issue ceiling bench.py reports as `secondary`.
 #pragma once
@@ -7,53 +7,148 @@
 
 namespace caf {
 
-// k_duo_rows<T, 0, DuoIoNull<T>>: no LDS traffic, no barriers, no global loads, no surface stores
+// an optimisation barrier on a value WITHOUT ordering constraints (not volatile: it may move freely with its operands,
+// it only hides the value's origin so that a synthesised operand is not constant-folded).  Operands that stand in for
+// per-row LOADS use the volatile keep() instead: like a load they must be produced once per row, not hoisted out of
+// the row loop (sixteen samples + thirty-two spectrum values held across the loop would spill)
+template <typename T>
+__device__ __forceinline__ void opaque(cpx<T> &x)
+{
+    asm("" : "+v"(x.x), "+v"(x.y));
+}
+
+// k_duo_rows<T, 0, DuoIoNull<T>>: no LDS traffic, no barriers, no global loads, no surface stores.  An LDS exchange
+// becomes a hand-over through sixteen registers of the policy object (identity "permutation"): every value a stage
+// produces still feeds the next stage, so nothing is dead and no scheduling fence is needed -- the compiler keeps the
+// product's arithmetic and is as free to schedule it as in the product.
 template <typename T>
 struct DuoIoNull {
-    cpx<T> *Lc;
-    const cpx<T> *twB;
+    using C = cpx<T>;
+    C *Lc;
+    const C *twB;
     const SeqLane &L;
-    __device__ __forceinline__ void hold(cpx<T> (&v)[16]) const
+    mutable C r[16];
+    __device__ __forceinline__ void put(const C (&v)[16]) const
     {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) keep(v[k]);
+        for (int k = 0; k < 16; ++k) r[k] = v[k];
     }
-    __device__ __forceinline__ void write_A(cpx<T> (&v)[16]) const { hold(v); }
-    __device__ __forceinline__ void read_A(cpx<T> (&v)[16]) const { hold(v); }
-    __device__ __forceinline__ void write_B(cpx<T> (&v)[16]) const { hold(v); }
-    __device__ __forceinline__ void read_B(cpx<T> (&v)[16]) const { hold(v); }
-    __device__ __forceinline__ void write_C(cpx<T> (&v)[16]) const { hold(v); }
-    __device__ __forceinline__ void read_C(cpx<T> (&v)[16]) const { hold(v); }
-    __device__ __forceinline__ void mul_twB(cpx<T> (&v)[16]) const
+    __device__ __forceinline__ void get(C (&v)[16]) const
     {
-        cpx<T> w = {T(0.6), T(0.8)};  // a register operand instead of the LDS table: same multiply count
-        keep(w);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = r[k];
+    }
+    __device__ __forceinline__ void write_A(const C (&v)[16]) const { put(v); }
+    __device__ __forceinline__ void read_A(C (&v)[16]) const { get(v); }
+    __device__ __forceinline__ void write_B(const C (&v)[16]) const { put(v); }
+    __device__ __forceinline__ void read_B(C (&v)[16]) const { get(v); }
+    __device__ __forceinline__ void write_C(const C (&v)[16]) const { put(v); }
+    __device__ __forceinline__ void read_C(C (&v)[16]) const { get(v); }
+    __device__ __forceinline__ void mul_twB(C (&v)[16]) const
+    {
+        C w = {T(0.6), T(0.8)};  // a register operand instead of the LDS table: same multiply count
+        opaque(w);
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], w);
     }
-    __device__ __forceinline__ void sink_A(int, cpx<T> x) const { keep(x); }
-    __device__ __forceinline__ void sync() const {}
-    __device__ __forceinline__ void fence() const {}
-    __device__ __forceinline__ void samples(cpx<T> (&a)[16], const __amdgpu_buffer_rsrc_t) const
+    __device__ __forceinline__ void sink_A(int k, C x) const { r[k] = x; }
+    // where the product has a barrier or a wave-level LDS fence the schedule keeps its phase boundary (a compile-time
+    // fence, no instruction): without them the compiler interleaves the stages of the whole row and spills
+    __device__ __forceinline__ void sync() const { __builtin_amdgcn_sched_barrier(0); }
+    __device__ __forceinline__ void fence() const { __builtin_amdgcn_sched_barrier(0); }
+    // stand-in for every loaded value: one opaque register pair (see SeqIoCut)
+    __device__ __forceinline__ C fake() const
     {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { a[q] = cpx<T>{T(q + 1), T(L.t)}; keep(a[q]); }
+        C w = {T(0.8), T(0.6)};
+        opaque(w);
+        return w;
     }
-    __device__ __forceinline__ cpx<T> sample(const __amdgpu_buffer_rsrc_t, int i) const
+    __device__ __forceinline__ void samples(C (&a)[16], const __amdgpu_buffer_rsrc_t) const
     {
-        cpx<T> x = {T(i + 1), T(L.t)};
-        keep(x);
-        return x;
-    }
-    __device__ __forceinline__ void spectrum(cpx<T> (&h)[16], const __amdgpu_buffer_rsrc_t, int chain) const
-    {
+        const C w = fake();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { h[k] = cpx<T>{T(1 + chain), T(k)}; keep(h[k]); }
+        for (int q = 0; q < 16; ++q) a[q] = w;
+    }
+    __device__ __forceinline__ C sample(const __amdgpu_buffer_rsrc_t, int) const { return fake(); }
+    __device__ __forceinline__ void spectrum(C (&h)[16], const __amdgpu_buffer_rsrc_t, int) const
+    {
+        const C w = fake();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h[k] = w;
     }
     template <typename V>
     __device__ __forceinline__ void store(const __amdgpu_buffer_rsrc_t, unsigned, V d) const
     {
-        asm volatile("" ::"v"(d));
+        asm volatile("" ::"v"(d));  // the row's results must stay live
+    }
+};
+
+// ---- k_seq_rows<T, PF, IO>: policies derived from the product's SeqIo<T> ------------------------------------------
+// bits of WHAT: 1 = no LDS traffic / barriers (hand-over through registers, as above), 2 = no global loads,
+// 4 = no surface stores (7 = VALU only)
+template <typename T, int WHAT>
+struct SeqIoCut : SeqIo<T> {
+    using C = cpx<T>;
+    using B = SeqIo<T>;
+    mutable C r[(WHAT & 1) ? 16 : 1];
+    __device__ __forceinline__ SeqIoCut(C *lc, const C *twb, const SeqLane &l) : B{lc, twb, l}
+    {
+        wfake = C{T(0.8), T(0.6)};
+        opaque(wfake);
+    }
+    // (the hand-over pins each value with a volatile asm, in order, like the original in-line ablation of rounds 1-2:
+    // the complex128 kernel sits at exactly 256 VGPRs, and with the stages free to interleave across the phase
+    // boundary the allocator spills 55-160 registers -- no ceiling of the product's instruction stream)
+    __device__ __forceinline__ void get(C (&v)[16]) const
+    {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            keep(r[(WHAT & 1) ? k : 0]);
+            v[k] = r[(WHAT & 1) ? k : 0];
+        }
+    }
+    __device__ __forceinline__ void sinkA(int k, C x) const { if constexpr (WHAT & 1) r[k] = x; else B::sinkA(k, x); }
+    __device__ __forceinline__ void sinkB(int k, C x) const { if constexpr (WHAT & 1) r[k] = x; else B::sinkB(k, x); }
+    __device__ __forceinline__ void sinkC(int k, C x) const { if constexpr (WHAT & 1) r[k] = x; else B::sinkC(k, x); }
+    __device__ __forceinline__ void readA(C (&v)[16]) const { if constexpr (WHAT & 1) get(v); else B::readA(v); }
+    __device__ __forceinline__ void readB(C (&v)[16]) const { if constexpr (WHAT & 1) get(v); else B::readB(v); }
+    __device__ __forceinline__ void readC(C (&v)[16]) const { if constexpr (WHAT & 1) get(v); else B::readC(v); }
+    __device__ __forceinline__ C twb(int k) const
+    {
+        if constexpr (WHAT & 1) { C w = {T(0.6), T(0.8)}; opaque(w); return w; }
+        else return B::twb(k);
+    }
+    // (cut: the phase boundary stays as a compile-time scheduling fence, see DuoIoNull)
+    __device__ __forceinline__ void sync() const { if constexpr (WHAT & 1) __builtin_amdgcn_sched_barrier(0); else B::sync(); }
+    __device__ __forceinline__ void fence() const { if constexpr (WHAT & 1) __builtin_amdgcn_sched_barrier(0); else B::fence(); }
+    // stand-in for every loaded value: ONE opaque register pair made at construction.  The multiplies the loaded values
+    // feed stay (their other operands differ), the sixteen-value arrays the product keeps in flight collapse to one
+    // pair -- fewer registers than the product, never more (per-call stand-ins made the allocator spill 37-60 VGPRs)
+    mutable C wfake;
+    __device__ __forceinline__ C fake(int) const { return wfake; }
+    __device__ __forceinline__ void samples(C (&a)[16], const __amdgpu_buffer_rsrc_t rs) const
+    {
+        if constexpr (WHAT & 2) {
+            const C x = fake(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = x;
+        } else B::samples(a, rs);
+    }
+    __device__ __forceinline__ C sample(const __amdgpu_buffer_rsrc_t rs, int i) const
+    {
+        if constexpr (WHAT & 2) return fake(i);
+        else return B::sample(rs, i);
+    }
+    __device__ __forceinline__ C spec(const __amdgpu_buffer_rsrc_t rs, unsigned voff, int k) const
+    {
+        if constexpr (WHAT & 2) return fake(k);
+        else return B::spec(rs, voff, k);
+    }
+    template <typename V>
+    __device__ __forceinline__ void store(const __amdgpu_buffer_rsrc_t rs, unsigned off, V d) const
+    {
+        if constexpr (WHAT & 4) asm volatile("" ::"v"(d));
+        else B::store(rs, off, d);
     }
 };
 

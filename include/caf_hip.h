@@ -158,7 +158,7 @@ int caf_plan_destroy(caf_plan *plan);
 const char *caf_plan_path(const caf_plan *plan);
 size_t caf_plan_rows(const caf_plan *plan);
 /* Name of the dominant (row) kernel the plan launches, as rocprofv3 prints it without
- * arguments, e.g. "caf::k_seq_rows<double, 0, 0, 15>" -- for matching bench.py's roofline
+ * arguments, e.g. "caf::k_seq_rows<double, 15, caf::SeqIo<double> >" -- for matching bench.py's roofline
  * object against profiles/. */
 const char *caf_plan_kernel_name(const caf_plan *plan);
 

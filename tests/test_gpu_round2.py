@@ -200,19 +200,19 @@ def test_config3_full_size_shards_equal_unsharded(eng, oracle):
 
 # --------------------------------------- (8) the product ignores measurement switches --
 def test_product_library_ignores_measurement_env(eng, oracle, golden, monkeypatch):
-    """CAF_STORE_MODE=13 selects a VALU-only ablation (wrong results) in libcaf_hip_measure.so;
+    """CAF_STORE_MODE=33 selects a VALU-only ablation (wrong results) in libcaf_hip_measure.so;
     libcaf_hip.so contains neither that instantiation nor any getenv: results are unchanged."""
     import subprocess
     import caf_cookoff_amd as caf
     syms = subprocess.run(["nm", "-D", "--undefined-only", str(caf.LIB_PATH)], capture_output=True, text=True).stdout
     assert "getenv" not in syms
-    for var, val in (("CAF_STORE_MODE", "13"), ("CAF_ROW_KERNEL", "2"), ("CAF_BIG_PATH", "1"), ("CAF_STATIC_ROWS", "1"),
+    for var, val in (("CAF_STORE_MODE", "33"), ("CAF_ROW_KERNEL", "2"), ("CAF_BIG_PATH", "1"), ("CAF_STATIC_ROWS", "1"),
                      ("CAF_WG_PER_CU", "1"), ("CAF_BIG_CHUNK", "7")):
         monkeypatch.setenv(var, val)
     fr = oracle.bench_shifts()
     nd, hs = oracle.load_pair(DATA, "chirp_0_raw.c64", oracle.KATS[0][1])
     plan = eng.plan(4096, fr, FS)
-    assert plan.kernel_name == "caf::k_seq_rows<double, 0, 0, 15>"
+    assert plan.kernel_name == "caf::k_seq_rows<double, 15, caf::SeqIo<double> >"
     plan.close()
     surf, ridx, rval, peak = eng.surface_arrays(nd, hs, fr, FS)
     assert (peak.freq, peak.idx) == (69.0, 202)
