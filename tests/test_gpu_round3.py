@@ -426,3 +426,30 @@ def test_short_host_api_soak():
     spec.loader.exec_module(mod)
     assert mod.run(4000, "c128", log=False) == 0
     assert mod.run(4000, "c64", log=False) == 0
+
+
+@pytest.mark.parametrize("n,dtype,split", [(64, "c128", False), (512, "c64", True), (8, "c128", True)])
+def test_small_path_streaming_slots(n, dtype, split, eng, oracle):
+    """caf_stream_* over a lane-group plan (n <= 512): every slot owns its haystack spectra, so slots (and the
+    branches of a split replay) run concurrently; 23 pairs (ragged against batch 4) against the oracle."""
+    import caf_cookoff_amd as caf
+    rng = np.random.default_rng(n)
+    cdt = np.complex128 if dtype == "c128" else np.complex64
+    tol = TOL64 if dtype == "c128" else TOL32
+    fr = np.linspace(-200.0, 200.0, 21)
+    nd = np.empty((23, n), dtype=cdt)
+    hs = np.empty((23, n), dtype=cdt)
+    for k in range(23):
+        nd[k], hs[k] = _planted(rng, n, FS, float(fr[k % 21]), k % max(1, n // 2), cdt)
+    plan = eng.plan(n, fr, FS, dtype=dtype)
+    assert plan.path == "small"
+    st = caf.Stream(plan, batch=4, nslots=3, want_surface=False, split=split)
+    peaks, ridx, rval = st.run(nd, hs, want_rows=True)
+    st.close()
+    plan.close()
+    for k in range(23):
+        _, oidx, oval = oracle.np_caf_surface(nd[k].astype(np.complex128), hs[k].astype(np.complex128), fr, FS, want_surface=False)
+        assert np.max(np.abs(rval[k].astype(np.float64) - oval)) <= tol * oval.max()
+        order = np.sort(oval)
+        if order[-1] - order[-2] > 4 * tol * oval.max():
+            assert int(peaks[k]["row"]) == int(np.argmax(oval))
