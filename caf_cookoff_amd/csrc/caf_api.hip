@@ -2281,18 +2281,25 @@ extern "C" int caf_multi_stream_run(caf_multi_stream *ms, const void *needles, c
     if (count && (!needles || !haystacks || !peaks)) return fail(CAF_ERR_BAD_ARG, "caf_multi_stream_run: NULL argument");
     const int nw = (int)ms->workers.size();
     std::vector<std::thread> threads;
+    bool spawn_failed = false;
     for (int i = 0; i < nw; ++i) {
         MultiWorker *w = &ms->workers[i];
         w->rc = CAF_OK;
         w->err.clear();
-        threads.emplace_back([=] {  // one host thread per device: the C ABI's contexts are single-threaded objects
-            size_t first = 0, stride = 1, items = 0;
-            caf_multi_stream_share(count, nw, i, &first, &stride, &items);
-            w->rc = stream_run_strided(w->stream, needles, haystacks, first, stride, items, peaks, row_idx, row_val);
-            if (w->rc) w->err = g_err;  // thread-local message of the worker thread
-        });
+        try {  // nothing may unwind across the C boundary: a thread that cannot be started fails the call instead
+            threads.emplace_back([=] {  // one host thread per device: the C ABI's contexts are single-threaded objects
+                size_t first = 0, stride = 1, items = 0;
+                caf_multi_stream_share(count, nw, i, &first, &stride, &items);
+                w->rc = stream_run_strided(w->stream, needles, haystacks, first, stride, items, peaks, row_idx, row_val);
+                if (w->rc) w->err = g_err;  // thread-local message of the worker thread
+            });
+        } catch (...) {
+            spawn_failed = true;
+            break;
+        }
     }
     for (auto &t : threads) t.join();
+    if (spawn_failed) return fail(CAF_ERR_NOMEM, "caf_multi_stream_run: could not start a worker thread (results are incomplete)");
     for (int i = 0; i < nw; ++i)
         if (ms->workers[i].rc)  // per-device error propagation: the first failing device, by position
             return fail(ms->workers[i].rc, "caf_multi_stream_run: worker %d (device %d): %s", i, ms->workers[i].device,
