@@ -275,6 +275,7 @@ def test_small_path_vs_oracle(n, dtype, eng, oracle):
     di = torch.zeros((B, 27), dtype=torch.int64, device="cuda")
     dv = torch.zeros((B, 27), dtype=tdt, device="cuda")
     dp = torch.zeros((B, 4), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()  # the tensors above were filled on torch's stream; the plan launches on the engine's own
     plan.surface_dev(dn.data_ptr(), dh.data_ptr(), B, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
     torch.cuda.synchronize()
     for b in range(B):
@@ -337,6 +338,7 @@ def test_fuzz_every_path_vs_oracle(case, eng, oracle):
     di = torch.zeros((batch, rows), dtype=torch.int64, device="cuda")
     dv = torch.zeros((batch, rows), dtype=tdt, device="cuda")
     dp = torch.zeros((batch, 4), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()  # the tensors above were filled on torch's stream; the plan launches on the engine's own
     plan.surface_dev(dn.data_ptr(), dh.data_ptr(), batch, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
     torch.cuda.synchronize()
     for b in range(batch):
@@ -381,7 +383,8 @@ def test_r32_variant_matches_oracle_and_product_kernel(eng, oracle, monkeypatch)
         di = torch.zeros((1, len(fr)), dtype=torch.int64, device="cuda")
         dv = torch.zeros((1, len(fr)), dtype=torch.float32, device="cuda")
         dp = torch.zeros((1, 4), dtype=torch.float64, device="cuda")
-        plan.surface_dev(dn.data_ptr(), dh.data_ptr(), 1, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
+        torch.cuda.synchronize()  # the tensors above were filled on torch's stream; the plan launches on the engine's own
+    plan.surface_dev(dn.data_ptr(), dh.data_ptr(), 1, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
         meng.synchronize()
         outs.append((ds[0].cpu().numpy(), di[0].cpu().numpy(), dv[0].cpu().numpy(), dp.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[0, 0]))
     plan.close()
