@@ -384,7 +384,7 @@ def test_r32_variant_matches_oracle_and_product_kernel(eng, oracle, monkeypatch)
         dv = torch.zeros((1, len(fr)), dtype=torch.float32, device="cuda")
         dp = torch.zeros((1, 4), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()  # the tensors above were filled on torch's stream; the plan launches on the engine's own
-    plan.surface_dev(dn.data_ptr(), dh.data_ptr(), 1, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
+        plan.surface_dev(dn.data_ptr(), dh.data_ptr(), 1, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
         meng.synchronize()
         outs.append((ds[0].cpu().numpy(), di[0].cpu().numpy(), dv[0].cpu().numpy(), dp.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[0, 0]))
     plan.close()
