@@ -24,6 +24,7 @@
 #include "kernels_duo4096.hpp"
 #include "kernels_chain.hpp"
 #include "kernels_small.hpp"
+#include "kernels_xcor.hpp"
 #include "kernels_generic.hpp"
 // Measurement build (-DCAF_MEASURE -> libcaf_hip_measure.so, used by tools/ and the variant
 // tests only): rejected kernel variants, ablation instantiations that produce WRONG results and
@@ -413,6 +414,43 @@ extern "C" int caf_apply_freq_shift_c64(caf_ctx *c, const float *in, size_t n, d
 }
 
 // -------------------------------------------------------------------- xcor --
+// full-length table e^{2 pi i m / n}, m < n, cached per (n, dtype) in the context (shared with the small-row plans)
+template <typename T>
+static int get_full_tw(caf_ctx *c, size_t n, int dt, void **out)
+{
+    auto key = std::make_pair(n, dt);
+    auto it = c->small_tabs.find(key);
+    if (it == c->small_tabs.end()) {
+        void *tw = nullptr;
+        HIPCHK(hipMalloc(&tw, n * sizeof(cpx<T>)));
+        k_twiddle<T><<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>((cpx<T> *)tw, n, n);
+        KCHK();
+        it = c->small_tabs.emplace(key, tw).first;
+    }
+    *out = it->second;
+    return CAF_OK;
+}
+
+// one-launch forms (kernels_xcor.hpp); returns false if n has none
+template <typename T>
+static bool xcor_one_launch(caf_ctx *c, const cpx<T> *a, const cpx<T> *b, const cpx<T> *tw, size_t n, cpx<T> *out)
+{
+    int lg = 0;
+    while (((size_t)1 << lg) < n) ++lg;
+#define XS(LG) case LG: k_xcor_small<T, LG><<<1, 64, 0, c->stream>>>(a, b, tw, out); return true;
+#define XC(LG) case LG: k_xcor_chain<T, LG><<<1, ChainGeo<LG>::W, 0, c->stream>>>(a, b, tw, out); return true;
+    switch (lg) {
+        XS(1) XS(2) XS(3) XS(4) XS(5) XS(6) XS(7) XS(8) XS(9) XS(10)
+        XC(11) XC(12) XC(13)
+    case 14:
+        if constexpr (sizeof(T) == 4) { k_xcor_chain<T, 14><<<1, ChainGeo<14>::W, 0, c->stream>>>(a, b, tw, out); return true; }
+        return false;  // complex128: a 16384-point chain does not fit in LDS
+    default: return false;
+    }
+#undef XS
+#undef XC
+}
+
 template <typename T>
 static int xcor_impl(caf_ctx *c, const T *a, const T *b, size_t n, T *out, int dt)
 {
@@ -421,15 +459,33 @@ static int xcor_impl(caf_ctx *c, const T *a, const T *b, size_t n, T *out, int d
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = n * sizeof(cpx<T>);
     int rc;
-    if ((rc = c->io_a.ensure(2 * bytes))) return rc;
-    if ((rc = c->io_b.ensure(2 * bytes))) return rc;
     if ((rc = c->pin_a.ensure(2 * bytes))) return rc;
     if ((rc = c->pin_b.ensure(bytes))) return rc;
+    memcpy(c->pin_a.h, a, bytes);                  // row 0 = a
+    memcpy((char *)c->pin_a.h + bytes, b, bytes);  // row 1 = b
+    if (n == 1) {  // out[0] = a[0] conj(b[0])   (a 1-point transform is the identity)
+        const T ar = a[0], ai = a[1], br = b[0], bi = b[1];
+        out[0] = ar * br + ai * bi;
+        out[1] = ai * br - ar * bi;
+        return CAF_OK;
+    }
+    if (n <= 16384 && !(n == 16384 && dt == CAF_C128)) {
+        // ONE launch: the kernel reads the pinned copies of a and b and writes the pinned result in place
+        void *twf = nullptr;
+        if ((rc = get_full_tw<T>(c, n, dt, &twf))) return rc;
+        if (xcor_one_launch<T>(c, (const cpx<T> *)c->pin_a.m, (const cpx<T> *)c->pin_a.m + n, (const cpx<T> *)twf, n,
+                               (cpx<T> *)c->pin_b.m)) {
+            KCHK();
+            HIPCHK(hipStreamSynchronize(c->stream));
+            memcpy(out, c->pin_b.h, bytes);
+            return CAF_OK;
+        }
+    }
+    if ((rc = c->io_a.ensure(2 * bytes))) return rc;
+    if ((rc = c->io_b.ensure(2 * bytes))) return rc;
     void *tw = nullptr;
     if ((rc = get_generic_tw<T>(c, n, dt, &tw))) return rc;
     cpx<T> *x = (cpx<T> *)c->io_a.p, *y = (cpx<T> *)c->io_b.p;
-    memcpy(c->pin_a.h, a, bytes);                  // row 0 = a
-    memcpy((char *)c->pin_a.h + bytes, b, bytes);  // row 1 = b
     const size_t in16 = (2 * bytes / 16 + 255) / 256;
     const unsigned cgrid = (unsigned)(in16 < 1 ? 1 : in16 > 1024 ? 1024 : in16);
     k_stage_copy<<<cgrid, 256, 0, c->stream>>>(CopyJobs{{c->pin_a.m, nullptr, nullptr}, {x, nullptr, nullptr}, {2 * bytes, 0, 0}});
@@ -456,6 +512,9 @@ extern "C" int caf_xcor_c64(caf_ctx *c, const float *a, const float *b, size_t n
 {
     return xcor_impl<float>(c, a, b, n, out, CAF_C64);
 }
+
+template <typename T>
+static int get_full_tw(caf_ctx *c, size_t n, int dt, void **out);
 
 // ----------------------------------------------------------- chain path set-up --
 // Which padded lengths the LDS-resident chain kernels (kernels_chain.hpp) cover: L = 2n = R * M
@@ -573,19 +632,7 @@ static int plan_build_tables(caf_plan *p)
     }
 #endif
     if (p->chain) return build_chain_tables<T>(p);
-    if (p->small) {
-        auto key = std::make_pair(p->L, dt);
-        auto it = c->small_tabs.find(key);
-        if (it == c->small_tabs.end()) {
-            void *tw = nullptr;
-            HIPCHK(hipMalloc(&tw, p->L * sizeof(cpx<T>)));
-            k_twiddle<T><<<(unsigned)((p->L + 255) / 256), 256, 0, c->stream>>>((cpx<T> *)tw, p->L, p->L);
-            KCHK();
-            it = c->small_tabs.emplace(key, tw).first;
-        }
-        p->s_twL = it->second;
-        return CAF_OK;
-    }
+    if (p->small) return get_full_tw<T>(c, p->L, dt, &p->s_twL);
 #ifdef CAF_MEASURE
     if (p->big) {
         if (!c->bigw256[dt]) {

@@ -96,8 +96,9 @@ int caf_apply_freq_shift_c64(caf_ctx *ctx, const float *in, size_t n,
 
 /* ---- a2-a4: xcor_rustfft::Xcor::{new,run}, xcor_rustfft.rs:29-78 ------------
  * out[k] = sum_m a[(m+k) mod n] * conj(b[m]) = IFFT(FFT(a)*conj(FFT(b))/n)
- * (unnormalised inverse).  Plans are cached inside the context per n, which is
- * what Xcor::new/clone provide. */
+ * (unnormalised inverse).  Tables are cached inside the context per n, which is
+ * what Xcor::new/clone provide.  One kernel launch for n = 2 ... 16384 (complex128:
+ * 8192) reading / writing pinned staging copies of a, b, out; radix-2 passes beyond. */
 int caf_xcor_c128(caf_ctx *ctx, const double *a, const double *b, size_t n, double *out);
 int caf_xcor_c64(caf_ctx *ctx, const float *a, const float *b, size_t n, float *out);
 

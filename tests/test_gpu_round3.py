@@ -456,3 +456,28 @@ def test_small_path_streaming_slots(n, dtype, split, eng, oracle):
         order = np.sort(oval)
         if order[-1] - order[-2] > 4 * tol * oval.max():
             assert int(peaks[k]["row"]) == int(np.argmax(oval))
+
+
+@pytest.mark.parametrize("dtype", ["c128", "c64"])
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768])
+def test_xcor_every_size_vs_oracle(n, dtype, eng, oracle):
+    """Xcor::run (xcor_rustfft.rs:51-78) for every power of two: one launch up to n = 16384 (kernels_xcor.hpp; complex128:
+    8192), radix-2 passes beyond; against the numpy restatement, plus the defining property out[k] = sum a[m+k] conj(b[m])
+    on a shifted copy (peak at the shift) and Xcor's length assertions."""
+    import caf_cookoff_amd as caf
+    rng = np.random.default_rng(7000 + n)
+    cdt = np.complex128 if dtype == "c128" else np.complex64
+    a = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cdt)
+    b = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cdt)
+    got = caf.Xcor(n, eng).run(a, b)
+    want = oracle.np_xcor(a.astype(np.complex128), b.astype(np.complex128))
+    assert got.dtype == cdt and got.shape == (n,)
+    tol = (1e-10 if dtype == "c128" else 2e-4) * max(1.0, np.max(np.abs(want)))
+    assert np.max(np.abs(got - want)) <= tol
+    if n >= 4:
+        sh = n // 3
+        got2 = eng.xcor(np.roll(b, sh), b)      # a[m] = b[m - sh]  ->  peak at k = sh
+        assert int(np.argmax(np.abs(got2))) == sh
+    # a second call with other data through the same cached tables
+    got3 = eng.xcor(b, a)
+    assert np.max(np.abs(got3 - oracle.np_xcor(b.astype(np.complex128), a.astype(np.complex128)))) <= tol
