@@ -1521,17 +1521,16 @@ static char *host_range_dev(caf_ctx *c, const void *ptr, size_t bytes)
     return it->second.dev + (q - it->first);
 }
 
-// device -> host copy into caller memory.  hipMemcpyAsync rejects a destination that straddles the edge of a
-// registered range ("invalid argument"), so the copy is cut at the edges of this context's registered ranges:
-// every piece lies wholly inside one range or wholly in ordinary memory.
-static int d2h_copy(caf_ctx *c, void *dst, const void *src, size_t bytes)
+// copy between caller (host) memory and a device buffer.  hipMemcpyAsync rejects a host range that straddles the edge
+// of a registered range ("invalid argument"), so the copy is cut at the edges of this context's registered ranges: every
+// piece lies wholly inside one range or wholly in ordinary memory.
+static int host_copy(caf_ctx *c, void *host, void *dev, size_t bytes, bool to_host)
 {
-    char *d = (char *)dst;
-    const char *s = (const char *)src;
+    char *h = (char *)host, *d = (char *)dev;
     size_t done = 0;
     while (done < bytes) {
         size_t piece = bytes - done;
-        char *q = d + done;
+        char *q = h + done;
         auto it = c->host_ranges.upper_bound(q);  // first range starting beyond q
         if (it != c->host_ranges.end() && (size_t)(it->first - q) < piece) piece = (size_t)(it->first - q);
         if (it != c->host_ranges.begin()) {
@@ -1539,11 +1538,13 @@ static int d2h_copy(caf_ctx *c, void *dst, const void *src, size_t bytes)
             char *end = in->first + in->second.bytes;
             if (q < end && (size_t)(end - q) < piece) piece = (size_t)(end - q);
         }
-        HIPCHK(hipMemcpyAsync(q, s + done, piece, hipMemcpyDeviceToHost, c->stream));
+        if (to_host) HIPCHK(hipMemcpyAsync(q, d + done, piece, hipMemcpyDeviceToHost, c->stream));
+        else HIPCHK(hipMemcpyAsync(d + done, q, piece, hipMemcpyHostToDevice, c->stream));
         done += piece;
     }
     return CAF_OK;
 }
+static int d2h_copy(caf_ctx *c, void *dst, const void *src, size_t bytes) { return host_copy(c, dst, (void *)src, bytes, true); }
 
 static void cpu_relax()
 {
@@ -1758,17 +1759,30 @@ template <typename T>
 static int view_impl(caf_ctx *c, const T *surface, size_t rows, size_t n, int view, T *out)
 {
     const size_t L = 2 * n, width = view == CAF_VIEW_GO ? L : n, off = view == CAF_VIEW_GO ? n : n / 2;
+    const size_t in_bytes = rows * L * sizeof(T), out_bytes = rows * width * sizeof(T);
     int rc;
-    if ((rc = c->io_surface.ensure(rows * L * sizeof(T)))) return rc;
-    if ((rc = c->io_a.ensure(rows * width * sizeof(T)))) return rc;
-    HIPCHK(hipMemcpyAsync(c->io_surface.p, surface, rows * L * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    // memory of caf_host_alloc / caf_host_register is read / written IN PLACE by the kernel (each value crosses PCIe once,
+    // under the kernel); anything else goes through the context's device buffers (the runtime's pageable path runs at the
+    // pinned rate once the pages are resident: tools/ubench/pcie_rates.hip)
+    const T *src = (const T *)host_range_dev(c, surface, in_bytes);
+    T *dst = (T *)host_range_dev(c, out, out_bytes);
+    if (!src) {
+        if ((rc = c->io_surface.ensure(in_bytes))) return rc;
+        if ((rc = host_copy(c, (void *)surface, c->io_surface.p, in_bytes, false))) return rc;
+        src = (const T *)c->io_surface.p;
+    }
+    const bool copy_out = dst == nullptr;
+    if (copy_out) {
+        if ((rc = c->io_a.ensure(out_bytes))) return rc;
+        dst = (T *)c->io_a.p;
+    }
     for (size_t r0 = 0; r0 < rows; r0 += 65535) {
         const size_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
-        k_view<T><<<dim3((unsigned)((width + 255) / 256), (unsigned)nr), 256, 0, c->stream>>>(
-            (const T *)c->io_surface.p + r0 * L, L, width, off, (T *)c->io_a.p + r0 * width);
+        k_view<T><<<dim3((unsigned)((width + 255) / 256), (unsigned)nr), 256, 0, c->stream>>>(src + r0 * L, L, width, off,
+                                                                                          dst + r0 * width);
     }
     KCHK();
-    HIPCHK(hipMemcpyAsync(out, c->io_a.p, rows * width * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    if (copy_out && (rc = d2h_copy(c, out, c->io_a.p, out_bytes))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return CAF_OK;
 }

@@ -481,3 +481,21 @@ def test_xcor_every_size_vs_oracle(n, dtype, eng, oracle):
     # a second call with other data through the same cached tables
     got3 = eng.xcor(b, a)
     assert np.max(np.abs(got3 - oracle.np_xcor(b.astype(np.complex128), a.astype(np.complex128)))) <= tol
+
+
+def test_views_in_place_on_pinned_memory(eng):
+    """caf_surface_view reads / writes memory of caf_host_alloc in place (no staging copy) and returns the same bits as
+    through ordinary memory; a source that straddles the edge of a registered range still works (copy cut at the edge)."""
+    rng = np.random.default_rng(3)
+    surf = rng.random((12, 256))
+    for view in ("go", "python"):
+        ref = eng.surface_view(surf, view)
+        psrc = eng.host_empty(surf.shape, np.float64)
+        psrc[:] = surf
+        assert np.array_equal(eng.surface_view(psrc, view), ref)
+        big = np.zeros((14, 256))
+        big[1:13] = surf
+        eng.host_register(big[:6])                      # the first six rows only: big[1:13] straddles the edge
+        assert np.array_equal(eng.surface_view(big[1:13], view), ref)
+        eng.host_unregister(big[:6])
+        del psrc
