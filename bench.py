@@ -437,7 +437,8 @@ def stream_case(eng, torch, freqs, total=1000):
     find_peak} from three on; the host reads completion from a pinned sequence word.  Reported forms:
       single_2slots / _3slots / _4slots   one surface per graph replay, native loop (caf_stream_run)
       split4_2slots                   four independent single-surface chains per replay
-      batched4_2slots                 one batched chain of four surfaces per replay (for comparison)
+      batched4_2slots / batched8_4slots   one batched chain of four / eight surfaces per replay (coarser granularity:
+                                      60-62 k surfaces/s with eight per replay and four slots, tools/stream_batch_sweep.py)
       single_2slots_three_kernels     round-2a form {spectrum, rows, find_peak} as three nodes (for comparison)
       single_2slots_python_loop       submit / wait driven from Python, step by step (for comparison)
     `value` = the FIXED form single_4slots (one surface per replay, four slots on probed-disjoint hardware
@@ -450,6 +451,7 @@ def stream_case(eng, torch, freqs, total=1000):
             ("single_2slots", 2, 1, False, False, True), ("single_3slots", 3, 1, False, False, True),
             ("single_4slots", 4, 1, False, False, True),
             ("split4_2slots", 2, 4, True, False, True), ("batched4_2slots", 2, 4, False, False, True),
+            ("batched8_4slots", 4, 8, False, False, True),
             ("single_2slots_three_kernels", 2, 1, False, True, True),
             ("single_2slots_python_loop", 2, 1, False, False, False)):
         v, us, okc = stream_run(plan, nd, hs, lags, total, nslots, batch, split, three, native)
