@@ -153,8 +153,8 @@ int caf_plan_create(caf_ctx *ctx, size_t n, const double *freqs_hz, size_t nfreq
                     caf_plan **out);
 int caf_plan_destroy(caf_plan *plan);
 /* Name of the kernel path the plan selected: "fused4096" (n = 4096), "chain" (every other n
- * from 1024 to 65536 in complex64 / 32768 in complex128: LDS-resident single-pass rows) or
- * "generic" (any other power of two: radix-2 passes over HBM).  The measurement build can
+ * from 1024 to 131072 in complex64 / 65536 in complex128: LDS-resident single-pass rows), "small"
+ * (n = 1 ... 512: lane-group rows, one launch) or "generic" (anything larger: radix-2 passes over HBM).  The measurement build can
  * also report "tiled65536" (round 1's three-pass n = 32768 form). */
 const char *caf_plan_path(const caf_plan *plan);
 size_t caf_plan_rows(const caf_plan *plan);
@@ -207,7 +207,7 @@ int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, 
  * four slots sustain the most single-surface replays per second on MI355X (the
  * slot streams are probed at creation so that they sit on separate hardware queues).  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
  * only (tau, f) + per-row peaks come back, as SURVEY.md section 8d prescribes.
- * Plans whose row kernel keeps its intermediate data on-chip ("fused4096", "chain") give
+ * Plans whose row kernel keeps its intermediate data on-chip ("fused4096", "chain", "small") give
  * every slot private device state, so slots execute concurrently.  Plans on the
  * "generic" path share the plan's pass workspaces: their slots run on ONE stream, in
  * submit order (slot k+1's H2D waits for slot k's kernels).
@@ -255,7 +255,9 @@ int caf_stream_run_stats(caf_stream *st, double *seconds4);
 /* Replay the slot's graph on the slot's stream (asynchronous). */
 int caf_stream_submit(caf_stream *st, int slot);
 /* Block until the slot's last submit finished; copies out `batch` caf_peak records and,
- * if non-NULL, batch*rows row indices / values (value type of the plan's dtype). */
+ * if non-NULL, batch*rows row indices / values (value type of the plan's dtype).  When this returns, the
+ * slot's surface slab (caf_stream_surface) is complete in device memory too: in the polled forms every wave of a
+ * row has waited for its surface stores before the row is counted towards the sequence word. */
 int caf_stream_wait(caf_stream *st, int slot, caf_peak *peaks, uint64_t *row_idx, void *row_val);
 /* Device address of the slot's surface slab ([batch][rows][2n]) or NULL. */
 void *caf_stream_surface(caf_stream *st, int slot);
