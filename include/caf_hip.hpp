@@ -184,6 +184,44 @@ class CafHipStream {
     caf_stream *stream_ = nullptr;
 };
 
+// The same over several GPUs (surface-parallel decomposition): one context + plan + stream per entry
+// of `devices` (an id may repeat), whole surfaces round-robin, answers in input order, no collective.
+class CafHipMultiStream {
+  public:
+    CafHipMultiStream(const std::vector<int> &devices, std::size_t n, const std::vector<double> &freqs_hz, uint32_t fs,
+                      int nslots = 3)
+        : n_(n)
+    {
+        check(caf_multi_stream_create(devices.data(), static_cast<int>(devices.size()), n, freqs_hz.data(), freqs_hz.size(), fs,
+                                      CAF_C128, nslots, &ms_),
+              "caf_multi_stream_create");
+    }
+    CafHipMultiStream(const CafHipMultiStream &) = delete;
+    CafHipMultiStream &operator=(const CafHipMultiStream &) = delete;
+    ~CafHipMultiStream() { caf_multi_stream_destroy(ms_); }
+    int devices() const { return caf_multi_stream_devices(ms_); }
+    std::vector<std::pair<double, std::size_t>> run(const std::vector<std::vector<Complex64>> &needles,
+                                                    const std::vector<std::vector<Complex64>> &haystacks)
+    {
+        if (needles.size() != haystacks.size()) throw std::runtime_error("CafHipMultiStream::run: needles vs haystacks");
+        std::vector<Complex64> a(needles.size() * n_), b(needles.size() * n_);
+        for (std::size_t k = 0; k < needles.size(); ++k) {
+            if (needles[k].size() != n_ || haystacks[k].size() != n_) throw std::runtime_error("CafHipMultiStream::run: length");
+            std::copy(needles[k].begin(), needles[k].end(), a.begin() + k * n_);
+            std::copy(haystacks[k].begin(), haystacks[k].end(), b.begin() + k * n_);
+        }
+        std::vector<caf_peak> pk(needles.size());
+        check(caf_multi_stream_run(ms_, a.data(), b.data(), needles.size(), pk.data(), nullptr, nullptr), "caf_multi_stream_run");
+        std::vector<std::pair<double, std::size_t>> out;
+        for (const caf_peak &p : pk) out.emplace_back(p.freq, static_cast<std::size_t>(p.idx));
+        return out;
+    }
+
+  private:
+    std::size_t n_;
+    caf_multi_stream *ms_ = nullptr;
+};
+
 // utils.rs:10-35: packed LE f32 I/Q pairs -> Complex64
 inline std::vector<Complex64> read_file_c64(const std::string &filename)
 {

@@ -3,6 +3,7 @@
 // lists, same exact-equality assertions on (freq, samp_idx)).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "caf_hip.hpp"
@@ -96,6 +97,42 @@ int main(int argc, char **argv)
         ASSERT_EQ(got[9].first, 61.5);
         ASSERT_EQ(got[9].second, 176);
         std::printf("test hip_stream_ten_pairs ... %s\n", failures == before ? "ok" : "FAILED");
+        // the same ten pairs, whole surfaces round-robin over TWO contexts on GPU 0 (caf_multi_stream_*: the
+        // surface-parallel multi-GPU driver, one host thread per context): same answers, in input order
+        CafHipMultiStream multi({0, 0}, nd[0].size(), shifts, 48000, 2);
+        auto got2 = multi.run(nd, hs);
+        const int before2 = failures;
+        ASSERT_EQ(multi.devices(), 2);
+        for (int k = 0; k < 10; ++k) {
+            ASSERT_EQ(got2[k].first, got[k].first);
+            ASSERT_EQ(got2[k].second, got[k].second);
+        }
+        std::printf("test hip_multi_stream_ten_pairs ... %s\n", failures == before2 ? "ok" : "FAILED");
+    }
+    // the literal drop-in call with the surface written in place into pinned memory (caf_host_alloc) and into a
+    // pageable buffer: same bits, and the row record points at the row's own maximum (mod.rs:143-151)
+    {
+        auto files = load_files(data_dir + "chirp_4_raw.c64", data_dir + "chirp_4_T+70samp_F+82.89Hz.c64");
+        auto shifts = gen_float_shifts(80.0, 100.0, 0.1);
+        const std::size_t n = files.first.size(), F = shifts.size(), L = 2 * n;
+        std::vector<double> pageable(F * L), val(F), val2(F);
+        std::vector<uint64_t> idx(F), idx2(F);
+        caf_peak pk, pk2;
+        void *pinned = nullptr;
+        check(caf_host_alloc(default_ctx(), F * L * sizeof(double), &pinned), "caf_host_alloc");
+        const double *nd = reinterpret_cast<const double *>(files.first.data());
+        const double *hs = reinterpret_cast<const double *>(files.second.data());
+        check(caf_surface_c128(default_ctx(), nd, hs, n, shifts.data(), F, 48000, pageable.data(), idx.data(), val.data(), &pk), "caf_surface_c128");
+        check(caf_surface_c128(default_ctx(), nd, hs, n, shifts.data(), F, 48000, static_cast<double *>(pinned), idx2.data(), val2.data(), &pk2), "caf_surface_c128 (in place)");
+        const int before = failures;
+        ASSERT_EQ(std::memcmp(pageable.data(), pinned, F * L * sizeof(double)), 0);
+        ASSERT_EQ(pk.freq, 82.9);   // test.rs:207-220
+        ASSERT_EQ(pk.idx, 70u);
+        ASSERT_EQ(pk2.freq, pk.freq);
+        ASSERT_EQ(pk2.idx, pk.idx);
+        ASSERT_EQ(pageable[static_cast<std::size_t>(pk.row) * L + pk.idx], pk.val);
+        check(caf_host_free(default_ctx(), pinned), "caf_host_free");
+        std::printf("test hip_surface_in_place ... %s\n", failures == before ? "ok" : "FAILED");
     }
     std::printf("test result: %s. %d failed\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;
