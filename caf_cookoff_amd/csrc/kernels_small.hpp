@@ -7,7 +7,7 @@
 // between the needle samples and the |.|^2 values happens in LDS and registers, in one launch:
 //
 //   u[i]  = conj(needle[i] * w^i), i < n; 0 for i >= n      (mixer mod.rs:46-65 + zero padding mod.rs:130;
-//                                                            the phasor is one f64 sincos of ph * i per sample)
+//                                                            phasors in f64: w^tl (w^TPR)^i, two sincos per lane and row)
 //   G     = IDFT_L(u) = conj(FFT_L(s))                      (positive exponent, unnormalised)
 //   P[k]  = Hs[k] * G[k],  Hs = FFT_L(haystack ++ 0) / L    (xcor_rustfft.rs:64-73; Hs once per surface: k_small_prepare)
 //   c     = IDFT_L(P);  mag[k] = |c[k]|^2                   (xcor_rustfft.rs:76, mod.rs:147)
@@ -138,21 +138,30 @@ __global__ __launch_bounds__(SmallGeo<LOGL>::THREADS) void k_small(const SmallAr
         const C *__restrict__ sig = A.sig + (size_t)bs * N;
         const double ph = PREP ? 0.0 : A.ph[r];
         // ---- mixer + conjugation + zero padding -> bx
+        // phasor of sample m = tl + TPR i:  w^m = w^tl (w^TPR)^i -- two f64 sincos per lane and row (base and step),
+        // then i successive f64 multiplications (i < 16: error <= ~2e-15, an order below the reference's own
+        // recurrence); rounded to T once per sample (never run the phasor in f32).  One sincos
+        // per SAMPLE cost as much as both transforms of the row.
+        double wr = 1.0, wi = 0.0, sr = 1.0, si = 0.0;
+        if constexpr (!PREP) {
+            sincos(ph * (double)tl, &wi, &wr);
+            sincos(ph * (double)TPR, &si, &sr);
+        }
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
             const int m = tl + TPR * i;
             C u = C{T(0), T(0)};
             if (m < N) {
                 const C a = sig[m];
-                if constexpr (PREP) {
-                    u = conj(a);
-                } else {
-                    double sn, cs;
-                    sincos(ph * (double)m, &sn, &cs);  // e^{j ph m}: the f64 phase, rounded once
-                    u = cmul_conj(a, C{(T)cs, (T)sn});
-                }
+                if constexpr (PREP) u = conj(a);
+                else u = cmul_conj(a, C{(T)wr, (T)wi});
             }
             bx[m] = u;
+            if constexpr (!PREP) {
+                const double nr = wr * sr - wi * si, ni = wr * si + wi * sr;
+                wr = nr;
+                wi = ni;
+            }
         }
         wave_lds_fence();
         C *res = small_idft<T, LOGL>(bx, by, twl, tl);
