@@ -254,20 +254,33 @@ static int get_generic_tw(caf_ctx *c, size_t L, int dt, void **out)
     return CAF_OK;
 }
 
-// log2(L) Stockham stages, ping-pong x<->y; returns the buffer holding the result.
+// Stockham passes over HBM, ping-pong x<->y: radix 16 while at least 16 points remain, then one radix-8 / 4 / 2 pass
+// (log16(L) passes instead of the log2(L) radix-2 stages of rounds 1-2); returns the buffer holding the result.
+template <typename T, int R>
+static void fft_pass(caf_ctx *c, const cpx<T> *x, cpx<T> *y, const cpx<T> *tw, size_t L, size_t nrows, size_t n_cur, int inverse)
+{
+    const size_t nb = L / R;
+    for (size_t r0 = 0; r0 < nrows; r0 += 65535) {
+        const size_t nr = nrows - r0 < 65535 ? nrows - r0 : 65535;
+        dim3 grid((unsigned)((nb + 255) / 256), (unsigned)nr);
+        k_fft_pass<T, R><<<grid, 256, 0, c->stream>>>(x + r0 * L, y + r0 * L, tw, L, n_cur, inverse);
+    }
+}
 template <typename T>
 static int run_fft(caf_ctx *c, cpx<T> *x, cpx<T> *y, const cpx<T> *tw, size_t L, size_t nrows,
                    int inverse, cpx<T> **res)
 {
-    const size_t half = L / 2;
-    for (size_t n_cur = L; n_cur >= 2; n_cur >>= 1) {
-        for (size_t r0 = 0; r0 < nrows; r0 += 65535) {
-            const size_t nr = nrows - r0 < 65535 ? nrows - r0 : 65535;
-            dim3 grid((unsigned)((half + 255) / 256), (unsigned)nr);
-            k_fft_stage<T><<<grid, 256, 0, c->stream>>>(x + r0 * L, y + r0 * L, tw, L, n_cur, inverse);
+    for (size_t n_cur = L; n_cur >= 2;) {
+        const size_t R = n_cur >= 16 ? 16 : n_cur;
+        switch (R) {
+        case 16: fft_pass<T, 16>(c, x, y, tw, L, nrows, n_cur, inverse); break;
+        case 8: fft_pass<T, 8>(c, x, y, tw, L, nrows, n_cur, inverse); break;
+        case 4: fft_pass<T, 4>(c, x, y, tw, L, nrows, n_cur, inverse); break;
+        default: fft_pass<T, 2>(c, x, y, tw, L, nrows, n_cur, inverse); break;
         }
         KCHK();
         std::swap(x, y);
+        n_cur /= R;
     }
     *res = x;
     return CAF_OK;
@@ -782,7 +795,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
     }
     if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";  // measurement build
     if (p->big) return f64 ? "caf::k_big_rows<double>" : "caf::k_big_rows<float>";  // measurement build
-    if (!p->fused) return f64 ? "caf::k_fft_stage<double>" : "caf::k_fft_stage<float>";
+    if (!p->fused) return f64 ? "caf::k_fft_pass<double, 16>" : "caf::k_fft_pass<float, 16>";
     if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 15, caf::SeqIo<double> >" : "caf::k_seq_rows<float, 15, caf::SeqIo<float> >";
     if (p->variant == 2) return f64 ? "caf::k_r8_rows<double, 0>" : "caf::k_r8_rows<float, 0>";
     if (p->variant == 3) return f64 ? "caf::k_duo_rows<double, 0, caf::DuoIo<double> >" : "caf::k_duo_rows<float, 0, caf::DuoIo<float> >";

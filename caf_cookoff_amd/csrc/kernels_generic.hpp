@@ -11,6 +11,7 @@
 // here -- the hot 400x8192 shape never takes this path.
 #pragma once
 #include "cplx.hpp"
+#include "kernels_fused4096.hpp"  // dft4 / dft16 butterflies for the radix-16 passes
 #include "../../include/caf_hip.h"
 
 namespace caf {
@@ -87,6 +88,61 @@ __global__ void k_fft_stage(const cpx<T> *__restrict__ x, cpx<T> *__restrict__ y
     if (!inverse) w.y = -w.y;
     y[row * L + q + s * (2 * p)] = a + b;
     y[row * L + q + s * (2 * p + 1)] = cmul(a - b, w);
+}
+
+// One Stockham pass of radix R (16 while at least 16 points remain, then 8 / 4 / 2) over `nbatch` length-L rows: x -> y,
+// the same recursion as the radix-2 stage above with R-point butterflies (dft16 / dft8 / dft4 in registers):
+//   butterfly (p, q), p < n_cur / R, q < s = L / n_cur:  in_j = x[q + s (p + (n_cur / R) j)],
+//   y[q + s (R p + k)] = DFT_R(in)_k * w^(p k),  w = e^{dir 2 pi i / n_cur}
+// log16(L) passes over HBM instead of log2(L): the path of every shape no LDS-resident kernel covers.
+// tw holds W_L^m for m < L/2 (W^(m + L/2) = -W^m); the negative-exponent direction conjugates in and out.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void k_fft_pass(const cpx<T> *__restrict__ x, cpx<T> *__restrict__ y,
+                                                  const cpx<T> *__restrict__ tw, size_t L, size_t n_cur, int inverse)
+{
+    const size_t bid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // < L / R
+    const size_t row = blockIdx.y;
+    if (bid >= L / R) return;
+    const size_t s = L / n_cur, m = n_cur / R, half = L >> 1;
+    const size_t p = bid / s, q = bid % s;
+    const cpx<T> *xr = x + row * L;
+    cpx<T> *yr = y + row * L;
+    cpx<T> v[16];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        v[j] = xr[q + s * (p + m * j)];
+        if (!inverse) v[j].y = -v[j].y;
+    }
+    if constexpr (R == 16) {
+        dft16(v);
+    } else if constexpr (R == 8) {
+        dft4(v[0], v[2], v[4], v[6]);
+        dft4(v[1], v[3], v[5], v[7]);
+        const cpx<T> o1 = mul_w8(v[3]), o2 = muli(v[5]), o3 = mul_w8_3(v[7]);
+        const cpx<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+        v[0] = e0 + o0; v[4] = e0 - o0;
+        v[1] = e1 + o1; v[5] = e1 - o1;
+        v[2] = e2 + o2; v[6] = e2 - o2;
+        v[3] = e3 + o3; v[7] = e3 - o3;
+    } else if constexpr (R == 4) {
+        dft4(v[0], v[1], v[2], v[3]);
+    } else {
+        const cpx<T> a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        cpx<T> o = v[k];
+        if (k && m > 1) {
+            const size_t e = (p * (size_t)k * s) % L;  // W_ncur^(p k) = W_L^(p k s)
+            cpx<T> w = tw[e < half ? e : e - half];
+            if (e >= half) { w.x = -w.x; w.y = -w.y; }
+            o = cmul(o, w);
+        }
+        if (!inverse) o.y = -o.y;
+        yr[q + s * ((size_t)R * p + k)] = o;
+    }
 }
 
 // C[row][k] = (H[b][k] * conj(S[row][k])) / L   (xcor_rustfft.rs:64-73; conj then

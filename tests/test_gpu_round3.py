@@ -499,3 +499,31 @@ def test_views_in_place_on_pinned_memory(eng):
         assert np.array_equal(eng.surface_view(big[1:13], view), ref)
         eng.host_unregister(big[:6])
         del psrc
+
+
+@pytest.mark.parametrize("dtype", ["c128", "c64"])
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 64, 128, 1024, 2048, 8192])
+def test_generic_radix16_passes_vs_oracle(n, dtype, oracle, monkeypatch):
+    """The path of every shape no LDS-resident kernel covers (n > 131072 / 65536 in the product): mixed-radix Stockham
+    passes over HBM -- radix 16 while at least 16 points remain, then 8 / 4 / 2 (k_fft_pass).  Forced here for small
+    and medium sizes through the measurement library (CAF_SMALL=0, CAF_CHAIN=0) so that every pass combination
+    (L = 2 ... 16384: remainders 2, 4, 8 and none) is checked against the oracle."""
+    import caf_cookoff_amd as caf
+    monkeypatch.setenv("CAF_SMALL", "0")
+    monkeypatch.setenv("CAF_CHAIN", "0")
+    meng = caf.Engine(0, lib=caf.MEASURE_LIB_PATH)
+    rng = np.random.default_rng(900 + n)
+    cdt = np.complex128 if dtype == "c128" else np.complex64
+    tol = TOL64 if dtype == "c128" else TOL32
+    fr = np.array([-50.0, 0.0, 12.5, 50.0, 333.0])
+    lag = 0 if n < 4 else n // 4
+    x, y = _planted(rng, n, FS, 12.5, lag, cdt)
+    plan = meng.plan(n, fr, FS, dtype=dtype)
+    assert plan.path == "generic" and "k_fft_pass" in plan.kernel_name
+    plan.close()
+    surf, ridx, rval, pk = meng.surface_arrays(x, y, fr, FS, dtype=dtype)
+    osurf, oidx, oval = oracle.np_caf_surface(x.astype(np.complex128), y.astype(np.complex128), fr, FS)
+    assert np.max(np.abs(surf - osurf)) <= tol * osurf.max()
+    if n >= 16:
+        assert (pk.freq, int(pk.idx)) == oracle.np_find_peak(fr, oidx, oval) == (12.5, lag)
+    meng.close()
