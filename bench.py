@@ -441,8 +441,11 @@ def stream_case(eng, torch, freqs, total=1000):
                                       60-62 k surfaces/s with eight per replay and four slots, tools/stream_batch_sweep.py)
       single_2slots_three_kernels     round-2a form {spectrum, rows, find_peak} as three nodes (for comparison)
       single_2slots_python_loop       submit / wait driven from Python, step by step (for comparison)
-    `value` = the FIXED form single_4slots (one surface per replay, four slots on probed-disjoint hardware
-    queues); the other forms are reported beside it, never selected from."""
+    `value` = the FIXED form batched8_4slots (eight surfaces per graph replay, four slots): the fastest form AND the one
+    whose rate does not depend on how the runtime happens to map the slot streams onto its hardware queues
+    (tools/stream_form_stability.py, profiles/r03_stream/form_stability.txt: 55.4-58.6 k surfaces/s over six
+    creations, against 38.7-55.0 k for single_4slots, whose single-surface chains serialise when two slots share a
+    queue); the other forms are reported beside it, never selected from."""
     from caf_cookoff_amd.synth import make_batch
     plan = eng.plan(N_SAMP, freqs, FS)
     nd, hs, lags, _ = make_batch(64, N_SAMP, FS, seed0=5000)
@@ -460,7 +463,7 @@ def stream_case(eng, torch, freqs, total=1000):
             forms[name]["host_thread"] = dict(getattr(stream_run, "last_host_us", {}))
     plan.close()
     abytes = algorithmic_bytes(1, 400, N_SAMP, "c128")
-    best = "single_4slots"
+    best = "batched8_4slots"
     return {"workload": f"{total} back-to-back 400x8192 complex128 surfaces from host memory, hipGraph replay per slot, "
                         "stage-in of inputs and stage-out of peaks included, surfaces left on the device (BASELINE configs[4])",
             "value": forms[best]["value"], "unit": "surfaces/s", "form": best, "forms": forms,

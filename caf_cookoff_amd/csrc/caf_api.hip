@@ -1904,6 +1904,9 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     HIPCHK(hipSetDevice(c->device));
     caf_stream *st = new (std::nothrow) caf_stream;
     if (!st) return fail(CAF_ERR_NOMEM, "out of host memory");
+    // which streams share a hardware queue is the runtime's business and changes when streams come and go: probe
+    // afresh for every caf_stream instead of trusting results from an earlier one (a few 0.2 ms probes per creation)
+    c->overlap.clear();
     st->plan = p;
     st->batch = batch;
     st->slots.resize(nslots);
