@@ -645,7 +645,19 @@ static int plan_build_tables(caf_plan *p)
     }
 #endif
     if (p->chain) return build_chain_tables<T>(p);
-    if (p->small) return get_full_tw<T>(c, p->L, dt, &p->s_twL);
+    if (p->small) {
+        if ((rc = get_full_tw<T>(c, p->L, dt, &p->s_twL))) return rc;
+        // k_small_rows (L >= 16): w^tl and w^TPR of every row, [rows][TPR + 1] complex f64.  Beyond 256 MiB the kernel
+        // runs the two sincos itself (same function, same arguments: same bits).
+        const size_t tpr = p->L / 16, entries = p->rows * (tpr + 1);
+        if (p->L >= 16 && p->rows && entries * sizeof(cpx<double>) <= ((size_t)256 << 20)) {
+            HIPCHK(hipMalloc(&p->d_phasor, entries * sizeof(cpx<double>)));
+            k_small_phasors<<<(unsigned)((entries + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows, (int)tpr,
+                                                                                    (cpx<double> *)p->d_phasor);
+            KCHK();
+        }
+        return CAF_OK;
+    }
 #ifdef CAF_MEASURE
     if (p->big) {
         if (!c->bigw256[dt]) {
@@ -790,7 +802,8 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
         static thread_local char name[64];
         int lg = 0;
         while (((size_t)1 << lg) < p->L) ++lg;
-        snprintf(name, sizeof name, "caf::k_small<%s, %d, false>", f64 ? "double" : "float", lg);
+        if (lg >= 4) snprintf(name, sizeof name, "caf::k_small_rows<%s, %d>", f64 ? "double" : "float", lg);
+        else snprintf(name, sizeof name, "caf::k_small<%s, %d, false>", f64 ? "double" : "float", lg);
         return name;
     }
     if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";  // measurement build
@@ -1231,8 +1244,14 @@ static int small_launch(caf_plan *p, SmallArgs<T> &a, const void *d_needle, cons
     a.row_val = (T *)d_rval;
     int rc;
     if ((rc = timing_mark(p))) return rc;
-    const size_t g1 = (total + G::RPW - 1) / G::RPW;
-    k_small<T, LOGL, false><<<(unsigned)(g1 < cap ? g1 : cap), G::THREADS, 0, c->stream>>>(a);
+    if constexpr (LOGL >= 4) {  // transforms in registers
+        using GR = SmallRowGeo<LOGL>;
+        const size_t g1 = (total + GR::RPW - 1) / GR::RPW;
+        k_small_rows<T, LOGL><<<(unsigned)(g1 < cap ? g1 : cap), GR::THREADS, 0, c->stream>>>(a, (const cpx<double> *)p->d_phasor);
+    } else {
+        const size_t g1 = (total + G::RPW - 1) / G::RPW;
+        k_small<T, LOGL, false><<<(unsigned)(g1 < cap ? g1 : cap), G::THREADS, 0, c->stream>>>(a);
+    }
     KCHK();
     return timing_mark(p);
 }

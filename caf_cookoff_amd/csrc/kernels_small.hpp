@@ -230,4 +230,240 @@ __global__ __launch_bounds__(SmallGeo<LOGL>::THREADS) void k_small(const SmallAr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Rows of L = 16 ... 1024 points with the transforms held in REGISTERS (round 3, second form).  k_small above
+// (still the kernel of L < 16 and of the haystack spectra) moves a row through LDS eight times per row at
+// L = 1024 -- mixer, three passes, spectrum product, three passes -- against an LDS whose STORES run at ~80 B/clk
+// per CU (MI355X_MICROARCH.md section LDS), with a 64-lane-to-one-bank store pattern in the first pass of every
+// transform (y[16 tl + k]) and 148 KiB of LDS per 256 threads: one wave per SIMD.  Here a lane keeps its 16
+// points in registers from the needle samples to |.|^2:
+//   * the mixer's own index pattern (sample tl + TPR j in slot j) IS the first pass' input pattern;
+//   * the last pass of a Stockham transform is in place (butterfly q reads and writes q + S k), and the 16 / R
+//     butterflies of a lane cover exactly tl + TPR j: the spectrum product and the second transform's first pass
+//     take them from the registers they are in, and the second transform's outputs are the lags tl + TPR j;
+//   * LDS is only the exchange between two passes of one transform (one for L = 32 ... 256, two for 512 / 1024;
+//     none for L = 16): a single buffer per row, every element e at e + (e >> 4) and rows L + L / 16 apart, which
+//     tools/lds_banks_small.py shows free of bank conflicts for every L and both dtypes;
+//   * twiddles sit in LDS per pass as [k - 1][p], so that consecutive lanes read consecutive entries;
+//   * the per-lane start phasor w^tl and the row's step w^TPR come from a table built with the plan by the same
+//     f64 sincos the kernel used to run twice per lane and row.
+// 512 threads: complex128 152 KiB of LDS (two waves per SIMD), complex64 76 KiB and <= 128 VGPRs (four).
+// The arithmetic (butterflies, twiddle products, their order) is that of k_small: bit-identical surfaces.
+template <int LOGL>
+struct SmallRowGeo {
+    static constexpr int L = 1 << LOGL, N = L / 2;
+    static constexpr int TPR = L / 16;          // lanes per row
+    static constexpr int THREADS = 512, WAVES = THREADS / 64;
+    static constexpr int RPW = THREADS / TPR;   // rows per workgroup
+    static constexpr int RPWV = 64 / TPR;       // rows per wave
+    static constexpr int ROWX = L + L / 16;     // exchange row stride (elements)
+    // |.|^2 staging rows (real elements) of the wave-wide surface store, tools/lds_banks_small.py
+    template <typename T>
+    static constexpr int ROWT = L >= 256 ? L : L + (sizeof(T) == 8 ? L / 16 : (L >= 32 ? L / 32 : 1));
+    // twiddle entries of the pass with sub-transform length ncur and of all passes after it
+    static constexpr int tw_entries(int ncur)
+    {
+        int n = 0;
+        while (ncur > 1) {
+            const int r = ncur >= 16 ? 16 : ncur, m = ncur / r;
+            if (m > 1) n += (r - 1) * m;
+            ncur /= r;
+        }
+        return n;
+    }
+    static constexpr int TWN = (tw_entries(L) + 15) & ~15;
+    // the surface leaves straight from the registers when a row's lanes cover >= 128 contiguous bytes per store
+    template <typename T>
+    static constexpr bool DIRECT = TPR * sizeof(T) >= 128;
+};
+
+template <typename T, int LOGL>
+constexpr size_t small_rows_lds_bytes()
+{
+    using G = SmallRowGeo<LOGL>;
+    return ((size_t)G::TWN + (size_t)G::WAVES * G::RPWV * G::ROWX) * sizeof(cpx<T>);
+}
+
+__device__ __forceinline__ int small_pad(int e) { return e + (e >> 4); }
+
+template <typename T, int R>
+__device__ __forceinline__ void small_dft_at(cpx<T> (&v)[16], int o)
+{
+    if constexpr (R == 16) {
+        dft16(v);
+    } else if constexpr (R == 8) {
+        dft8(v[o], v[o + 1], v[o + 2], v[o + 3], v[o + 4], v[o + 5], v[o + 6], v[o + 7]);
+    } else if constexpr (R == 4) {
+        dft4(v[o], v[o + 1], v[o + 2], v[o + 3]);
+    } else {
+        const cpx<T> a = v[o], b = v[o + 1];
+        v[o] = a + b;
+        v[o + 1] = a - b;
+    }
+}
+
+// per-pass twiddle tables [k - 1][p] = W_L^(p k S), p < M, from the natural-order W_L table
+template <typename T, int LOGL, int NCUR, int TWOFF>
+__device__ __forceinline__ void small_rows_tw_fill(cpx<T> *tw, const cpx<T> *__restrict__ twL, int tid)
+{
+    using G = SmallRowGeo<LOGL>;
+    constexpr int L = G::L, R = NCUR >= 16 ? 16 : NCUR, S = L / NCUR, M = NCUR / R;
+    if constexpr (M > 1) {
+        for (int i = tid; i < (R - 1) * M; i += G::THREADS) {
+            const int k = i / M + 1, p = i % M;
+            tw[TWOFF + i] = twL[(p * k * S) & (L - 1)];
+        }
+        small_rows_tw_fill<T, LOGL, NCUR / R, TWOFF + (R - 1) * M>(tw, twL, tid);
+    }
+}
+
+// The passes of one transform from sub-transform length NCUR on.  In: v[b R + j] = x[q + S (p + M j)] of butterfly
+// b (bid = tl + b TPR, p = bid / S, q = bid % S) -- for the first pass that is x[tl + TPR j] in slot j.  Out:
+// slot j = X[tl + TPR j].  Same butterflies, twiddles and order of operations as small_pass.
+template <typename T, int LOGL, int NCUR, int TWOFF>
+__device__ __forceinline__ void small_rows_tf(cpx<T> (&v)[16], cpx<T> *xb, const cpx<T> *tw, int tl)
+{
+    using G = SmallRowGeo<LOGL>;
+    using C = cpx<T>;
+    constexpr int L = G::L, TPR = G::TPR, R = NCUR >= 16 ? 16 : NCUR, S = L / NCUR, M = NCUR / R, NBF = 16 / R;
+#pragma unroll
+    for (int b = 0; b < NBF; ++b) small_dft_at<T, R>(v, b * R);
+    if constexpr (M > 1) {
+#pragma unroll
+        for (int b = 0; b < NBF; ++b) {
+            const int p = (tl + b * TPR) / S;
+#pragma unroll
+            for (int k = 1; k < R; ++k) v[b * R + k] = cmul(v[b * R + k], tw[TWOFF + (k - 1) * M + p]);
+        }
+#pragma unroll
+        for (int b = 0; b < NBF; ++b) {
+            const int bid = tl + b * TPR, p = bid / S, q = bid % S;
+#pragma unroll
+            for (int k = 0; k < R; ++k) xb[small_pad(q + S * (R * p + k))] = v[b * R + k];
+        }
+        wave_lds_fence();
+        constexpr int NC2 = NCUR / R, R2 = NC2 >= 16 ? 16 : NC2, S2 = L / NC2, M2 = NC2 / R2, NBF2 = 16 / R2;
+#pragma unroll
+        for (int b = 0; b < NBF2; ++b) {
+            const int bid = tl + b * TPR, p = bid / S2, q = bid % S2;
+#pragma unroll
+            for (int j = 0; j < R2; ++j) v[b * R2 + j] = xb[small_pad(q + S2 * (p + M2 * j))];
+        }
+        wave_lds_fence();
+        small_rows_tf<T, LOGL, NC2, TWOFF + (R - 1) * M>(v, xb, tw, tl);
+    } else {
+        // last pass (p = 0, q = bid, S = L / R): output k of butterfly b is X[tl + TPR (b + k NBF)]
+        C t[16];
+#pragma unroll
+        for (int b = 0; b < NBF; ++b)
+#pragma unroll
+            for (int k = 0; k < R; ++k) t[b + k * NBF] = v[b * R + k];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = t[j];
+    }
+}
+
+// w^tl (tl < TPR) and w^TPR of every row of a plan: [rows][TPR + 1]
+__global__ __launch_bounds__(256) void k_small_phasors(const double *__restrict__ ph, int rows, int tpr, cpx<double> *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * (tpr + 1)) return;
+    const int r = (int)(i / (tpr + 1)), t = (int)(i % (tpr + 1));
+    double s, c;
+    sincos(ph[r] * (double)t, &s, &c);
+    out[i] = cpx<double>{c, s};
+}
+
+template <typename T, int LOGL>
+__global__ __launch_bounds__(SmallRowGeo<LOGL>::THREADS, sizeof(T) == 8 ? 2 : 4) void k_small_rows(
+    const SmallArgs<T> A, const cpx<double> *__restrict__ phz)
+{
+    using G = SmallRowGeo<LOGL>;
+    using C = cpx<T>;
+    constexpr int L = G::L, TPR = G::TPR, RPWV = G::RPWV, ROWT = G::template ROWT<T>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[small_rows_lds_bytes<T, LOGL>()];
+    C *const tw = reinterpret_cast<C *>(smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rwv = lane / TPR, tl = lane % TPR;
+    C *const xw = tw + G::TWN + (size_t)wave * (RPWV * G::ROWX);  // this wave's rows
+    C *const xb = xw + (size_t)rwv * G::ROWX;
+    small_rows_tw_fill<T, LOGL, L, 0>(tw, A.twL, tid);
+    __syncthreads();
+    const int ngroups = (A.total + G::RPW - 1) / G::RPW;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int g0 = grp * G::RPW + wave * RPWV;  // first row of this wave
+        const int g = g0 + rwv;
+        const bool live = g < A.total;
+        const int gc = live ? g : A.total - 1;  // idle groups redo the last row and store nothing
+        const int bs = gc / A.rows, r = gc - bs * A.rows;
+        const C *__restrict__ sig = A.sig + (size_t)bs * G::N;
+        const C *__restrict__ hs = A.spec + (size_t)bs * L;
+        // ---- mixer + conjugation + zero padding (mod.rs:46-65,130): slot j = conj(needle[m] w^m), m = tl + TPR j
+        double wr, wi, sr, si;
+        if (phz) {
+            const cpx<double> w0 = phz[(size_t)r * (TPR + 1) + tl], st = phz[(size_t)r * (TPR + 1) + TPR];
+            wr = w0.x; wi = w0.y; sr = st.x; si = st.y;
+        } else {
+            const double ph = A.ph[r];
+            sincos(ph * (double)tl, &wi, &wr);
+            sincos(ph * (double)TPR, &si, &sr);
+        }
+        C v[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // m < N <=> j < 8
+            v[j] = cmul_conj(sig[tl + TPR * j], C{(T)wr, (T)wi});
+            const double nr = wr * sr - wi * si, ni = wr * si + wi * sr;
+            wr = nr;
+            wi = ni;
+        }
+#pragma unroll
+        for (int j = 8; j < 16; ++j) v[j] = C{T(0), T(0)};
+        small_rows_tf<T, LOGL, L, 0>(v, xb, tw, tl);  // G = IDFT_L(u) = conj(FFT_L(s))
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = cmul(v[j], hs[tl + TPR * j]);  // xcor_rustfft.rs:64-73
+        small_rows_tf<T, LOGL, L, 0>(v, xb, tw, tl);  // xcor_rustfft.rs:76
+        T mg[16];
+        T bv = T(0);
+        uint32_t bi = 0u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            mg[j] = norm_sqr(v[j]);  // mod.rs:147
+            if (mg[j] > bv) { bv = mg[j]; bi = (uint32_t)(tl + TPR * j); }  // first strictly greater (mod.rs:148-151): lags ascend with j
+        }
+        if (A.surface) {
+            if constexpr (G::template DIRECT<T>) {
+                if (live) {
+                    T *const out = A.surface + (size_t)g * L + tl;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) out[TPR * j] = mg[j];
+                }
+            } else {
+                // through the wave's (now idle) exchange rows, so that the wave stores contiguous runs: its RPWV rows
+                // are adjacent in the surface
+                T *const st = reinterpret_cast<T *>(xw);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) st[rwv * ROWT + tl + TPR * j] = mg[j];
+                wave_lds_fence();
+                T *const out0 = A.surface + (size_t)g0 * L;
+#pragma unroll
+                for (int e0 = 0; e0 < RPWV * L; e0 += 64) {
+                    const int e = e0 + lane, rr = e / L, k = e % L;
+                    if (g0 + rr < A.total) out0[e] = st[rr * ROWT + k];
+                }
+                wave_lds_fence();  // the next group's exchange writes vs these reads
+            }
+        }
+        // reduce over the row's TPR lanes (a power of two, aligned inside the wave); equal values keep the lower lag
+#pragma unroll
+        for (int msk = TPR >> 1; msk >= 1; msk >>= 1) {
+            const T ov = shfl_xor_t<T>(bv, msk);
+            const uint32_t oi = (uint32_t)__shfl_xor((int)bi, msk, 64);
+            arg_merge(bv, bi, ov, oi);
+        }
+        if (live && tl == 0) {
+            A.row_idx[g] = bi;
+            A.row_val[g] = bv;
+        }
+    }
+}
+
 }  // namespace caf
