@@ -1413,7 +1413,8 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
     if (!p || !d_needle || !d_hay || !d_peak) return fail(CAF_ERR_BAD_ARG, "caf_surface_dev: NULL argument");
     if (p->rows && (!d_ridx || !d_rval)) return fail(CAF_ERR_BAD_ARG, "caf_surface_dev: row outputs are NULL");
     if (batch == 0) return CAF_OK;
-    if (batch * (p->rows ? p->rows : 1) > 0x7fffffffu) return fail(CAF_ERR_BAD_ARG, "caf_surface_dev: batch too large");
+    // (the row kernels index rows with int, some after rounding the count up to a workgroup's worth of rows)
+    if (batch * (p->rows ? p->rows : 1) > 0x7fffffffu - 65536u) return fail(CAF_ERR_BAD_ARG, "caf_surface_dev: batch too large");
     caf_ctx *c = p->ctx;
     HIPCHK(hipSetDevice(c->device));
     int rc;

@@ -234,12 +234,76 @@ def test_multi_stream_error_propagation(eng):
 
 # ------------------------------------------------------ short inputs: lane-group rows, n = 1 ... 512 --
 @pytest.mark.parametrize("dtype", ["c128", "c64"])
+@pytest.mark.parametrize("n", [8, 64, 512])
+def test_small_rows_many_groups_vs_oracle(n, dtype, eng, oracle):
+    """k_small_rows with more rows than resident workgroups' worth of one pass and a ragged tail: 3 surfaces x 1031
+    rows (a prime; 512 / (n / 8) rows per workgroup), every value of the surfaces against the numpy oracle."""
+    import torch
+    rng = np.random.default_rng(7000 + n)
+    cdt, tdt = (np.complex128, torch.float64) if dtype == "c128" else (np.complex64, torch.float32)
+    tol = TOL64 if dtype == "c128" else TOL32
+    fs, F, B = 48000, 1031, 3
+    fr = np.linspace(-400.0, 400.0, F)
+    nd = (rng.standard_normal((B, n)) + 1j * rng.standard_normal((B, n))).astype(cdt)
+    hs = (rng.standard_normal((B, n)) + 1j * rng.standard_normal((B, n))).astype(cdt)
+    plan = eng.plan(n, fr, fs, dtype=dtype)
+    assert plan.kernel_name.startswith("caf::k_small_rows<")
+    dn, dh = torch.from_numpy(nd).cuda(), torch.from_numpy(hs).cuda()
+    ds = torch.full((B, F, 2 * n), -1.0, dtype=tdt, device="cuda")
+    di = torch.zeros((B, F), dtype=torch.int64, device="cuda")
+    dv = torch.zeros((B, F), dtype=tdt, device="cuda")
+    dp = torch.zeros((B, 4), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    plan.surface_dev(dn.data_ptr(), dh.data_ptr(), B, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
+    torch.cuda.synchronize()
+    got, gi, gv = ds.cpu().numpy(), di.cpu().numpy(), dv.cpu().numpy()
+    for b in range(B):
+        ob, oi, ov = oracle.np_caf_surface(nd[b].astype(np.complex128), hs[b].astype(np.complex128), fr, fs)
+        assert np.max(np.abs(got[b] - ob)) <= tol * ob.max()
+        assert np.array_equal(gi[b], np.argmax(got[b], axis=1))                   # first maximum of its own row
+        assert np.array_equal(gv[b], got[b][np.arange(F), gi[b]])
+    plan.close()
+
+
+def test_small_rows_without_phasor_table_bit_equal(eng):
+    """k_small_rows takes w^tl and w^TPR from a per-plan table up to 256 MiB and runs the two f64 sincos itself beyond
+    (same function, same arguments): 270 000 rows at n = 512 (peaks only) are past the limit; 64 of those rows through
+    a plan that has the table must give the same bits."""
+    import torch
+    rng = np.random.default_rng(99)
+    n, fs, F = 512, 48000, 270000
+    fr = np.linspace(-2000.0, 2000.0, F)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    y = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    dn, dh = torch.from_numpy(x[None]).cuda(), torch.from_numpy(y[None]).cuda()
+    dp = torch.zeros((1, 4), dtype=torch.float64, device="cuda")
+    big = eng.plan(n, fr, fs, dtype="c64")
+    bi = torch.zeros((1, F), dtype=torch.int64, device="cuda")
+    bv = torch.zeros((1, F), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    big.surface_dev(dn.data_ptr(), dh.data_ptr(), 1, None, bi.data_ptr(), bv.data_ptr(), dp.data_ptr())
+    torch.cuda.synchronize()
+    big.close()
+    sel = np.arange(131000, 131064)
+    small = eng.plan(n, fr[sel], fs, dtype="c64")
+    si = torch.zeros((1, 64), dtype=torch.int64, device="cuda")
+    sv = torch.zeros((1, 64), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    small.surface_dev(dn.data_ptr(), dh.data_ptr(), 1, None, si.data_ptr(), sv.data_ptr(), dp.data_ptr())
+    torch.cuda.synchronize()
+    small.close()
+    assert np.array_equal(bi.cpu().numpy()[0, sel], si.cpu().numpy()[0])
+    assert np.array_equal(bv.cpu().numpy()[0, sel], sv.cpu().numpy()[0])
+    assert float(sv.max()) > 0
+
+
+@pytest.mark.parametrize("dtype", ["c128", "c64"])
 @pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512])
 def test_small_path_vs_oracle(n, dtype, eng, oracle):
     """kernels_small.hpp ("any power of two", xcor_rustfft.rs:2): every n below the chain kernels' range runs as
     lane-group rows in ONE launch; surface vs the numpy oracle (1e-6 / 1e-3 of the maximum), row argmax where the
-    oracle's row has a clear winner, global peak exact; ragged row counts (rows per workgroup = 256 / max(1, n / 8)
-    does not divide them), several surfaces per launch through the device API."""
+    oracle's row has a clear winner, global peak exact; ragged row counts (rows per workgroup = 512 / (n / 8) from n = 8
+    on, 256 / max(1, n / 8) below, does not divide them), several surfaces per launch through the device API."""
     import torch
     import caf_cookoff_amd as caf
     rng = np.random.default_rng(1000 + n)
