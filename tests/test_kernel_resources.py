@@ -61,3 +61,21 @@ def test_chain_kernels_register_shape():
         limit = {2: 30, 4: 30 if is_f64 else 50, 8: 70 if is_f64 else 90, 16: 10 if is_f64 else 60}[r]
         assert int(f["VGPRs Spill"]) <= limit, (name, f["VGPRs Spill"])
     assert seen == 13  # 6 complex128 + 7 complex64 instantiations (R = 16: n = 65536 complex128, n = 131072 complex64)
+
+
+def test_small_row_kernels_register_shape():
+    """k_small_rows (kernels_small.hpp, n = 8 ... 512): the launch code assumes 512-thread workgroups with
+    complex128 at two waves per SIMD (one workgroup of <= 160 KiB of LDS per CU) and complex64 at four (two
+    workgroups per CU: <= 128 VGPRs, <= 80 KiB each); spills stay marginal."""
+    usage = _usage()
+    seen = 0
+    for name, f in usage.items():
+        if "k_small_rows" not in name:
+            continue
+        seen += 1
+        is_f64 = "k_small_rowsId" in name
+        lds = int(f["LDS Size [bytes/block]"])
+        assert int(f["Occupancy [waves/SIMD]"]) == (2 if is_f64 else 4), name
+        assert lds <= (160 if is_f64 else 80) * 1024, (name, lds)
+        assert int(f["VGPRs Spill"]) <= (0 if is_f64 else 8), (name, f["VGPRs Spill"])
+    assert seen == 14  # LOGL = 4 ... 10, both dtypes
