@@ -3,20 +3,21 @@
 // xcor_rustfft.rs:2 promises "any power of two"; below n = 1024 a row is too small for a workgroup (the chain
 // kernels of kernels_chain.hpp start at n = 1024) and used to take 2 log2(L) + 3 launches over HBM.  Here a row
 // belongs to a GROUP OF LANES of one wave -- TPR = max(1, L / 16) lanes, 16 points per lane (L points when
-// L < 16: one lane owns a whole row) -- and a 256-thread workgroup carries 256 / TPR rows at once.  Everything
-// between the needle samples and the |.|^2 values happens in LDS and registers, in one launch:
+// L < 16: one lane owns a whole row) -- and a workgroup carries many rows at once, everything in one launch:
 //
 //   u[i]  = conj(needle[i] * w^i), i < n; 0 for i >= n      (mixer mod.rs:46-65 + zero padding mod.rs:130;
-//                                                            phasors in f64: w^tl (w^TPR)^i, two sincos per lane and row)
+//                                                            phasors in f64: w^tl (w^TPR)^i)
 //   G     = IDFT_L(u) = conj(FFT_L(s))                      (positive exponent, unnormalised)
-//   P[k]  = Hs[k] * G[k],  Hs = FFT_L(haystack ++ 0) / L    (xcor_rustfft.rs:64-73; Hs once per surface: k_small_prepare)
+//   P[k]  = Hs[k] * G[k],  Hs = FFT_L(haystack ++ 0) / L    (xcor_rustfft.rs:64-73; Hs once per surface: k_small<.., true>)
 //   c     = IDFT_L(P);  mag[k] = |c[k]|^2                   (xcor_rustfft.rs:76, mod.rs:147)
 //   first-strictly-greater argmax over the row (mod.rs:143-151), surface store, row peak.
 //
-// The transform is a Stockham autosort FFT (natural order in and out) between two LDS buffers of the row, radix
-// 16 while at least 16 points remain, then one radix-8 / 4 / 2 pass; a lane does 16 / R butterflies per pass.
-// All lanes of a row sit in one wave, so the exchanges between passes need no workgroup barrier (LDS operations
-// of a wave execute in order).  Twiddles come from a W_L table in LDS (one per workgroup).
+// Two kernels share this arithmetic (Stockham autosort passes, radix 16 while at least 16 points remain, then one
+// radix-8 / 4 / 2 pass; all lanes of a row sit in one wave, so no exchange needs a workgroup barrier):
+//   k_small       the first form: the row lives in two LDS buffers, every pass reads and writes LDS.  Still the
+//                 kernel of L < 16 (n = 1, 2, 4) and of the haystack spectra of every n <= 512;
+//   k_small_rows  (second half of this file) L = 16 ... 1024: the row lives in registers, LDS is only the
+//                 exchange between two passes of a transform.  2-3.4x the first form's rate.
 #pragma once
 #include "kernels_chain.hpp"
 
