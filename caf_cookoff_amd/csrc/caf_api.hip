@@ -2359,7 +2359,7 @@ extern "C" int caf_multi_stream_create(const int *device_ids, int ndev, size_t n
         w.device = device_ids[i];
         int rc = caf_ctx_create(w.device, &w.ctx);
         if (!rc) rc = caf_plan_create(w.ctx, n, freqs_hz, nfreq, fs, dtype, 0, nfreq, &w.plan);
-        if (!rc) rc = caf_stream_create(w.plan, 1, nslots, 0, &w.stream);
+        if (!rc) rc = caf_stream_create(w.plan, 8, nslots, 0, &w.stream);  // eight surfaces per replay: profiles/r03_stream/form_stability.txt
         if (rc) {  // g_err of this thread holds the failing call's message
             caf_multi_stream_destroy(ms);
             return rc;

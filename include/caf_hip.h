@@ -265,7 +265,8 @@ void *caf_stream_surface(caf_stream *st, int slot);
 /* ---- surface-parallel multi-GPU streaming (second decomposition) ---------------
  * Whole surfaces round-robin over devices: the unit of work the reference's callers hand out when many
  * surfaces are wanted (one caf_surface call per iteration, benches/caf_bench.rs:150-168; independent pool tasks,
- * mod.rs:404-457).  One caf_ctx + caf_plan + caf_stream (one surface per replay, `nslots` slots) per entry of
+ * mod.rs:404-457).  One caf_ctx + caf_plan + caf_stream (eight surfaces per replay -- the form whose rate does not depend on
+ * how the runtime maps slot streams to hardware queues -- `nslots` slots) per entry of
  * device_ids -- an id may repeat: two contexts on one GPU -- each driven by its own host thread during a run.
  * Pair k of the caller's arrays goes to worker k % ndev; peaks / row_idx / row_val come back in INPUT order.
  * No collective: a surface's (tau, f) is complete on the device that computed it.  If workers fail, the call

@@ -189,7 +189,8 @@ def test_in_row_exact_tie_lowest_lag_wins(dtype, n, eng):
 def test_multi_stream_two_contexts_on_one_gpu(dtype, eng, oracle):
     """caf_multi_stream_*: whole surfaces round-robin over workers, one host thread each (here: TWO contexts
     on device 0, the closest a one-GPU box gets to two devices).  37 pairs (odd, ragged), results in input
-    order, every (tau, f) and every row peak against the oracle; equal to a single caf_stream run bit for bit."""
+    order, every (tau, f) and every row peak against the oracle; equal to a single caf_stream run of the same form
+    (eight surfaces per replay) bit for bit."""
     import caf_cookoff_amd as caf
     from caf_cookoff_amd.synth import make_batch
     cdt = np.complex128 if dtype == "c128" else np.complex64
@@ -199,7 +200,9 @@ def test_multi_stream_two_contexts_on_one_gpu(dtype, eng, oracle):
     assert ms.ndev == 2
     peaks, ridx, rval = ms.run(nd, hs, want_rows=True)
     plan = eng.plan(4096, fr, FS, dtype=dtype)
-    st = caf.Stream(plan, batch=1, nslots=2, want_surface=False)
+    # (the workers stream eight surfaces per replay; a one-surface-per-replay stream runs the one-launch kernel, whose
+    #  haystack spectrum differs from k_seq_prepare's in the last bit)
+    st = caf.Stream(plan, batch=8, nslots=2, want_surface=False)
     p1, i1, v1 = st.run(nd, hs, want_rows=True)
     st.close()
     plan.close()

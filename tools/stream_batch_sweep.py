@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """configs[4] with more than one surface per graph replay: surfaces/s of caf_stream_run for (batch, slots) combinations,
-batched chains (one k_seq_prepare + one row kernel + one find_peak per replay).  usage: stream_batch_sweep.py [count] [rounds]"""
+batched chains (one k_seq_prepare + one row kernel + one find_peak per replay).  usage: stream_batch_sweep.py [count] [rounds] [batch:slots ...]"""
 import sys
 import time
 from pathlib import Path
@@ -20,6 +20,8 @@ reps = (count + 15) // 16
 nd, hs = np.tile(nd16, (reps, 1))[:count], np.tile(hs16, (reps, 1))[:count]
 lags = np.tile(np.asarray(lags16), reps)[:count]
 forms = [(1, 4), (4, 3), (8, 2), (8, 3), (8, 4), (16, 2), (16, 3), (16, 4), (32, 2), (32, 3), (64, 2), (64, 3)]
+if len(sys.argv) > 3:
+    forms = [tuple(int(x) for x in a.split(":")) for a in sys.argv[3:]]
 streams = [caf.Stream(plan, batch=b, nslots=s, want_surface=True) for b, s in forms]
 rates = [[] for _ in forms]
 oks = [0] * len(forms)
