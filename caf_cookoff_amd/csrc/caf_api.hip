@@ -1191,7 +1191,8 @@ static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_ha
     a.row_val = (T *)d_rval;
     if ((rc = timing_mark(p))) return rc;
 #ifdef CAF_MEASURE
-    // CAF_CHAIN_ABL (bit mask, kernels_chain.hpp ChainLane): ablations of the configs[3] kernel, WRONG results
+    // CAF_CHAIN_ABL (bit mask of measure/kernels_ablate.hpp ChainIoCut): ablations of the configs[3] kernel, WRONG results;
+    // 200: two butterflies per thread (correct results, measured and rejected)
     if constexpr (sizeof(T) == 4) {
         const int abl = (int)measure_env("CAF_CHAIN_ABL", 0);
         if (abl && p->clogm == 14 && R == 4) {
@@ -1203,12 +1204,8 @@ static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_ha
             case 16: k_chain_rows<T, 14, 4, 1, 16><<<grid, W, 0, c->stream>>>(a, phasor); break;
             case 30: k_chain_rows<T, 14, 4, 1, 30><<<grid, W, 0, c->stream>>>(a, phasor); break;
             case 31: k_chain_rows<T, 14, 4, 1, 31><<<grid, W, 0, c->stream>>>(a, phasor); break;
-            case 256: k_chain_rows<T, 14, 4, 1, 256><<<grid, W, 0, c->stream>>>(a, phasor); break;  // looped row (correct results)
-            case 32: k_chain_rows<T, 14, 4, 1, 32><<<grid, W, 0, c->stream>>>(a, phasor); break;  // wave priorities by SIMD slot (correct results)
-            case 64: k_chain_rows<T, 14, 4, 1, 64><<<grid, W, 0, c->stream>>>(a, phasor); break;  // wave priorities by wave % 4 (correct results)
             case 159: k_chain_rows<T, 14, 4, 1, 159><<<grid, W, 0, c->stream>>>(a, phasor); break;  // arithmetic only
             case 128: k_chain_rows<T, 14, 4, 1, 128><<<grid, W, 0, c->stream>>>(a, phasor); break;  // no LDS chain traffic
-            case 62: k_chain_rows<T, 14, 4, 1, 62><<<grid, W, 0, c->stream>>>(a, phasor); break;  // priorities + no global memory
             case 200: k_chain_rows<T, 14, 4, 2, 0><<<grid, W / 2, 0, c->stream>>>(a, phasor); break;  // two butterflies per thread (correct results)
             default: return fail(CAF_ERR_BAD_ARG, "CAF_CHAIN_ABL=%d: no such ablation", abl);
             }

@@ -209,13 +209,53 @@ __device__ __forceinline__ void small_stage(cpx<T> (&v)[16])
 // (parity-green, CAF_CHAIN_ABL=200 of the measurement build): NB = 2 is SLOWER, 1.60 vs 1.39 ms, and
 // 1.02 vs 0.91 ms without global memory: two waves per SIMD with 116 spilled registers, and a
 // 4-bit lgkmcnt cannot wait for "all but the other slot's 32 operations".
-// ABL (measurement build only, WRONG results, timing only): bit 0 = no workgroup barriers, bit 1 = no
-// haystack-spectrum loads, bit 2 = no slab traffic, bit 3 = no needle loads, bit 4 = no surface stores, bit 7 = no LDS chain traffic;
-// bits 5 / 6 (correct results): static wave priorities, see k_chain_rows.
+//
+// Every memory access of a row -- chain elements in LDS, the barrier after a non-local exchange, needle samples,
+// haystack-spectrum values, the scratch slab, surface stores -- goes through a policy class.  The product instantiates
+// ChainIo<T> only (ABL = 0 in every kernel name of libcaf_hip.so); the measurement library derives ablations from it
+// (measure/kernels_ablate.hpp: ChainIoCut<T, mask>, WRONG results, timing only) and instantiates the same bodies.
+template <typename T>
+struct ChainIo {
+    using C = cpx<T>;
+    static constexpr bool wg_barriers = true;  // non-local exchanges end in a workgroup barrier
+    __device__ __forceinline__ static void lds_st(C *Lc, int pos, C x) { Lc[pos] = x; }
+    __device__ __forceinline__ static C lds_ld(const C *Lc, int pos) { return Lc[pos]; }
+    // needle sample of register row q, nonzero block j, butterfly beta (the indices only name the value)
+    __device__ __forceinline__ static C sample(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int, int, int)
+    {
+        return bload(rs, voff, soff, (C *)nullptr);
+    }
+    // haystack-spectrum values k, k + 1 of a chain
+    __device__ __forceinline__ static void spec2(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int, C &h0, C &h1)
+    {
+        bload2(rs, voff, soff, h0, h1);
+    }
+    // this workgroup's scratch slab, array arr, register row i
+    __device__ __forceinline__ static void slab_st(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, C x)
+    {
+        bstore(rs, voff, soff, x);
+    }
+    __device__ __forceinline__ static C slab_ld(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int, int)
+    {
+        return bload(rs, voff, soff, (C *)nullptr);
+    }
+    __device__ __forceinline__ static void surf_st(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, T m)
+    {
+        store_one_aux<CAF_AUX_SC1>(rs, voff, soff, m);
+    }
+};
+template <typename T, int ABL>
+struct ChainIoFor;  // ABL != 0: measure/kernels_ablate.hpp
+template <typename T>
+struct ChainIoFor<T, 0> {
+    using type = ChainIo<T>;
+};
+
 template <typename T, int LOGM, int NB = 1, int ABL = 0>
 struct ChainLane {
     using G = ChainGeo<LOGM>;
     using C = cpx<T>;
+    using IO = typename ChainIoFor<T, ABL>::type;
     static constexpr int TH = G::W / NB;  // threads per workgroup
     static_assert(G::W % NB == 0 && (TH % 64 == 0 || NB == 1), "slots must be whole waves apart");
     static_assert(G::NST < 3 || G::local_after(1), "exchanges after stage 1 are assumed wave-local");
@@ -272,22 +312,14 @@ struct ChainLane {
         }
     }
 
-    // chain element accessors (ABL bit 7, measurement: no LDS data traffic)
-    __device__ __forceinline__ void st(int pos, C x) const
-    {
-        if constexpr (ABL & 128) keep(x);
-        else Lc[pos] = x;
-    }
-    __device__ __forceinline__ C ld(int pos) const
-    {
-        if constexpr (ABL & 128) { C x = C{T(pos), T(1)}; keep(x); return x; }
-        else return Lc[pos];
-    }
+    // chain element accessors
+    __device__ __forceinline__ void st(int pos, C x) const { IO::lds_st(Lc, pos, x); }
+    __device__ __forceinline__ C ld(int pos) const { return IO::lds_ld(Lc, pos); }
     // synchronise the exchange that follows radix-16 stage s
     template <int S>
     __device__ __forceinline__ void sync_after() const
     {
-        if constexpr (G::local_after(S) || (ABL & 1))
+        if constexpr (G::local_after(S) || !IO::wg_barriers)
             wave_lds_fence();
         else
             __syncthreads();
@@ -383,7 +415,7 @@ struct ChainLane {
     __device__ __forceinline__ void inv_steps(C (&v)[NB][16]) const
     {
         static_assert(S >= 1, "stage 0 is finished by inverse()");
-        constexpr bool local = G::local_after(S - 1) || (ABL & 1);
+        constexpr bool local = G::local_after(S - 1) || !IO::wg_barriers;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if constexpr (S == G::NST - 1) {
@@ -438,11 +470,8 @@ __device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[
     const C *psA = ph + 48 + 16 * rA, *psB = ph + 48 + 16 * rB;
     const unsigned voff = (unsigned)(beta * sizeof(C));
     C k1 = C{T(1), T(0)}, k2 = k1, k3 = k1, k4 = k1, k5 = k1, k6 = k1, k7 = k1;
-    constexpr bool RT = (ABL & 256) != 0;  // rA is a run-time value (looped R = 4 rows, measurement variant)
-    if constexpr (R == 4) {
-        k1 = ph[112];  // w^M
-        if constexpr (RT) { if (rA) k1 = C{k1.y, -k1.x}; }  // b = (-i)^rA w^M a1: x_rA = a0 + b, x_(rA+2) = a0 - b
-    }
+    using IO = typename ChainIoFor<T, ABL>::type;
+    if constexpr (R == 4) k1 = ph[112];  // w^M
     if constexpr (R == 8) {              // kappa_{rA, 1..3}
         k1 = ph[176 + 3 * rA];
         k2 = ph[176 + 3 * rA + 1];
@@ -459,12 +488,7 @@ __device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[
             const int q = GQ * grp + u;
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                if constexpr (ABL & 8) {
-                    a[grp & 1][u][j] = C{T(q + 1 + j), T(beta)};
-                    keep(a[grp & 1][u][j]);
-                    continue;
-                }
-                a[grp & 1][u][j] = bload(rs_sig, voff, (unsigned)((M * j + W * q) * sizeof(C)), (C *)nullptr);
+                a[grp & 1][u][j] = IO::sample(rs_sig, voff, (unsigned)((M * j + W * q) * sizeof(C)), q, j, beta);
             }
         }
     };
@@ -480,14 +504,9 @@ __device__ __forceinline__ void chain_input_pair(cpx<T> (&vA)[16], cpx<T> (&vB)[
                 vA[q] = cmul_conj(x, psA[q]);
                 vB[q] = cmul_conj(x, psB[q]);
             } else if constexpr (R == 4) {
-                const C b = cmul(a[grp & 1][u][1], k1);
-                if constexpr (RT) {
-                    vA[q] = cmul_conj(x + b, psA[q]);
-                    vB[q] = cmul_conj(x - b, psB[q]);
-                } else {  // rA = 0: x +- b;  rA = 1: x -+ i b
-                    vA[q] = cmul_conj(rA == 0 ? x + b : sub_i(x, b), psA[q]);
-                    vB[q] = cmul_conj(rA == 0 ? x - b : add_i(x, b), psB[q]);
-                }
+                const C b = cmul(a[grp & 1][u][1], k1);  // rA = 0: x +- b;  rA = 1: x -+ i b
+                vA[q] = cmul_conj(rA == 0 ? x + b : sub_i(x, b), psA[q]);
+                vB[q] = cmul_conj(rA == 0 ? x - b : add_i(x, b), psB[q]);
             } else if constexpr (R == 8) {
                 // x_rA = E + O, x_(rA+4) = E - O;  E = a0 + kappa_2 a2,  O = kappa_1 a1 + kappa_3 a3
                 const C E = cfma(x, a[grp & 1][u][2], k2);
@@ -629,15 +648,14 @@ __device__ __forceinline__ void chain_run(cpx<T> (&v)[NB][16], const ChainLane<T
             C h[8];
 #pragma unroll
             for (int k = 0; k < 8; k += 2) {
-                if constexpr (ABL & 2) { h[k] = C{T(1), T(k)}; h[k + 1] = C{T(k), T(1)}; keep(h[k]); keep(h[k + 1]); continue; }
-                bload2(rs_spec, voff, (unsigned)(2 * G::W * (4 * half + k / 2) * sizeof(C)), h[k], h[k + 1]);
+                ChainLane<T, LOGM, NB, ABL>::IO::spec2(rs_spec, voff, (unsigned)(2 * G::W * (4 * half + k / 2) * sizeof(C)), k, h[k], h[k + 1]);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[b][8 * half + k] = cmul(v[b][8 * half + k], h[k]);  // xcor_rustfft.rs:64-73
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if constexpr (R < 8 && !(ABL & 256)) {  // r is a compile-time constant after inlining: chain 0 keeps its cheaper twiddle form
+    if constexpr (R < 8) {  // r is a compile-time constant after inlining: chain 0 keeps its cheaper twiddle form
         if (r) {
             L.inverse(v, [&](int b, int k, C x) { const TwFold<T> fpost(L.tw[b], post[b]); return twA_k(x, k, L.tw[b], fpost); });
         } else {
@@ -670,19 +688,12 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
     constexpr int W = G::W, M = G::M, Lp = R * M, NS_IN = R * M / 2;
     constexpr int NWV = (W / NB + 63) / 64;  // waves per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char smem[chain_lds_bytes<T, LOGM>()];
+    using IO = typename ChainIoFor<T, ABL>::type;
     const ChainLane<T, LOGM, NB, ABL> L(smem, A.twM);
     unsigned char *const scratch = smem + chain_lds_bytes<T, LOGM>() - 256;  // per-wave argmax partials
     T *const sv = reinterpret_cast<T *>(scratch);
     uint32_t *const si = reinterpret_cast<uint32_t *>(scratch + 128);
     const int lane = L.t & 63, wave = L.t >> 6;
-    if constexpr ((ABL & 96) != 0) {
-        // measurement: static issue priorities for the waves that share a SIMD (wave w sits on SIMD w % 4), so
-        // that they run staggered between workgroup barriers instead of in the same phase
-        const int slot = (ABL & 64) ? (__builtin_amdgcn_readfirstlane(wave) & 3) : ((__builtin_amdgcn_readfirstlane(wave) >> 2) & 3);
-        if (slot == 0) __builtin_amdgcn_s_setprio(3);
-        else if (slot == 1) __builtin_amdgcn_s_setprio(2);
-        else if (slot == 2) __builtin_amdgcn_s_setprio(1);
-    }
     __syncthreads();
 
     for (int g = blockIdx.x; g < A.total; g += gridDim.x) {
@@ -712,8 +723,7 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
             const T m = norm_sqr(c);  // mod.rs:147
             bi[j] = m > bv[j] ? i * NB + b : bi[j];
             bv[j] = vmax(bv[j], m);
-            if constexpr (ABL & 16) { asm volatile("" ::"v"(m)); return; }
-            store_one_aux<CAF_AUX_SC1>(rs_out, (unsigned)(L.beta[b] * sizeof(T)), (unsigned)((M * j + W * i) * sizeof(T)), m);
+            IO::surf_st(rs_out, (unsigned)(L.beta[b] * sizeof(T)), (unsigned)((M * j + W * i) * sizeof(T)), m);
         };
 
         if constexpr (R == 2) {
@@ -745,12 +755,10 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
             const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(A.slab + (size_t)blockIdx.x * (NARR * 16 * W)), 0, NARR * 16 * W * (int)sizeof(C), 0x00020000);
             auto slab_st = [&](int arr, int i, int b, C x) {
-                if constexpr (ABL & 4) { keep(x); return; }
-                bstore(rs_slab, (unsigned)(L.beta[b] * sizeof(C)), (unsigned)((arr * 16 + i) * W * sizeof(C)), x);
+                IO::slab_st(rs_slab, (unsigned)(L.beta[b] * sizeof(C)), (unsigned)((arr * 16 + i) * W * sizeof(C)), x);
             };
             auto slab_ld = [&](int arr, int i, int b) -> C {
-                if constexpr (ABL & 4) { C x = C{T(i), T(arr)}; keep(x); return x; }
-                return bload(rs_slab, (unsigned)(L.beta[b] * sizeof(C)), (unsigned)((arr * 16 + i) * W * sizeof(C)), (C *)nullptr);
+                return IO::slab_ld(rs_slab, (unsigned)(L.beta[b] * sizeof(C)), (unsigned)((arr * 16 + i) * W * sizeof(C)), arr, i);
             };
             if constexpr (R == 16) {
                 // COMPUTE PHASE: the eight chain pairs (r', r'+8) as iterations of a run-time loop (the chain code exists
@@ -771,7 +779,7 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
                         const unsigned so = (unsigned)(r * 16 * W * sizeof(C));
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
-                            bstore(rs_slab, (unsigned)(L.beta[0] * sizeof(C)), so + (unsigned)(i * W * sizeof(C)), cur[0][i]);
+                            IO::slab_st(rs_slab, (unsigned)(L.beta[0] * sizeof(C)), so + (unsigned)(i * W * sizeof(C)), cur[0][i]);
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { const C t = cur[0][i]; cur[0][i] = oth[0][i]; oth[0][i] = t; }
                     }
@@ -784,7 +792,7 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
                     C z[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        z[r] = bload(rs_slab, (unsigned)(L.beta[0] * sizeof(C)), (unsigned)((r * 16 + i) * W * sizeof(C)), (C *)nullptr);
+                        z[r] = IO::slab_ld(rs_slab, (unsigned)(L.beta[0] * sizeof(C)), (unsigned)((r * 16 + i) * W * sizeof(C)), r, i);
 #pragma unroll
                     for (int r = 1; r < 16; ++r) z[r] = cmul(z[r], L.Lc[(i * r) & 255]);
                     dft16(z);
@@ -792,9 +800,10 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
                     for (int j = 0; j < 16; ++j) emit(j, i, 0, z[j]);
                 }
                 __syncthreads();  // the table's positions belong to the next row's chain again
-            } else if constexpr (R == 8 || (ABL & 256) != 0) {
-                // LOOPED form (R = 8 always; R = 4 as a measurement variant, where it is 1-2 % slower than the unrolled
-                // form below; R = 8 gains 14 %: 2.10 vs 2.44 ms per 2048 x 131072 complex64 rows, 74 vs 206 spills): the R/2 chain pairs are iterations of a run-time loop and the two chains of a pair
+            } else if constexpr (R == 8) {
+                // LOOPED form (R = 4 in this form ran 1-2 % slower than the unrolled form below -- measured in rounds 2-3,
+                // no longer in the source; R = 8 gains 14 %: 2.10 vs 2.44 ms per 2048 x 131072 complex64 rows, 74 vs 206
+                // spills): the R/2 chain pairs are iterations of a run-time loop and the two chains of a pair
                 // iterations of an inner one, so the chain code (input stage, forward, spectrum product, inverse:
                 // ~2.8 k instructions) exists once instead of R times.  Fully inlined the R = 4 row is ~90 KB of
                 // code and the R = 8 row ~180 KB, against a 64 KB instruction cache shared by two CUs.
@@ -808,8 +817,7 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
                     //                   j = 2j'+1 : sum_r' (i)^(j' r') thQ^r' Q_r',  thQ = W_128^(i+16)
                     //   i.e. two radix-4 combinations like the R = 4 one.  Pair order 0, 2, 1, 3; slab arrays:
                     //   [0],[1] = P0, Q0 -> aP, bP;  [2],[3] = aQ, bQ;  [4],[5] = P1, Q1;  P3, Q3 stay in registers.
-                    // R = 4: pairs 0, 1 as in the unrolled form below
-                    const int rp = __builtin_amdgcn_readfirstlane(R == 4 ? it : (((it & 1) << 1) | (it >> 1)));
+                    const int rp = __builtin_amdgcn_readfirstlane(((it & 1) << 1) | (it >> 1));
                     chain_input_pair<T, LOGM, R, ABL>(cur[0], oth[0], rs_sig, rp, rp + NP, L.beta[0], ph);
 #pragma clang loop unroll(disable)
                     for (int c = 0; c < 2; ++c) {
@@ -817,78 +825,51 @@ __launch_bounds__(ChainGeo<LOGM>::W / NB, chain_wps_v(LOGM, sizeof(cpx<T>), NB))
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { const C t = cur[0][i]; cur[0][i] = oth[0][i]; oth[0][i] = t; }
                     }
-                    // cur = y'_rp, oth = y'_(rp + R/2)
-                    if constexpr (R == 4) {
-                        if (it == 0) {
+                    // cur = y'_rp, oth = y'_(rp + 4)
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                C a, bb;
-                                bfly_w(cur[0][i], oth[0][i], W64C[2 * i], W64S[2 * i], a, bb);
-                                slab_st(0, i, 0, a);
-                                slab_st(1, i, 0, bb);
-                            }
-                        } else {
+                    for (int i = 0; i < 16; ++i) {  // P, Q in place of y'_r', y'_(r'+4)
+                        C P, Q;
+                        bfly_w(cur[0][i], oth[0][i], W32C16[i], W32S16[i], P, Q);
+                        cur[0][i] = P;
+                        oth[0][i] = Q;
+                    }
+                    if (it == 0) {
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                C cc, dd;
-                                bfly_w(cur[0][i], oth[0][i], W64C[2 * i], W64S[2 * i], cc, dd);
-                                const C a = slab_ld(0, i, 0), bb = slab_ld(1, i, 0);
-                                C c0, c2, c1, c3;
-                                bfly_w(a, cc, W64C[i], W64S[i], c0, c2);
-                                bfly_w(bb, dd, -W64S[i], W64C[i], c1, c3);
-                                emit(0, i, 0, c0);
-                                emit(1, i, 0, c1);
-                                emit(2, i, 0, c2);
-                                emit(3, i, 0, c3);
-                                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                            }
+                        for (int i = 0; i < 16; ++i) { slab_st(0, i, 0, cur[0][i]); slab_st(1, i, 0, oth[0][i]); }
+                    } else if (it == 1) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            C aP, bP, aQ, bQ;
+                            bfly_w(slab_ld(0, i, 0), cur[0][i], W128C[2 * i], W128S[2 * i], aP, bP);
+                            bfly_w(slab_ld(1, i, 0), oth[0][i], W128C[2 * i + 32], W128S[2 * i + 32], aQ, bQ);
+                            slab_st(0, i, 0, aP);
+                            slab_st(1, i, 0, bP);
+                            slab_st(2, i, 0, aQ);
+                            slab_st(3, i, 0, bQ);
+                            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                         }
+                    } else if (it == 2) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { slab_st(4, i, 0, cur[0][i]); slab_st(5, i, 0, oth[0][i]); }
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {  // P, Q in place of y'_r', y'_(r'+4)
-                            C P, Q;
-                            bfly_w(cur[0][i], oth[0][i], W32C16[i], W32S16[i], P, Q);
-                            cur[0][i] = P;
-                            oth[0][i] = Q;
-                        }
-                        if (it == 0) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) { slab_st(0, i, 0, cur[0][i]); slab_st(1, i, 0, oth[0][i]); }
-                        } else if (it == 1) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                C aP, bP, aQ, bQ;
-                                bfly_w(slab_ld(0, i, 0), cur[0][i], W128C[2 * i], W128S[2 * i], aP, bP);
-                                bfly_w(slab_ld(1, i, 0), oth[0][i], W128C[2 * i + 32], W128S[2 * i + 32], aQ, bQ);
-                                slab_st(0, i, 0, aP);
-                                slab_st(1, i, 0, bP);
-                                slab_st(2, i, 0, aQ);
-                                slab_st(3, i, 0, bQ);
-                                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                            }
-                        } else if (it == 2) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) { slab_st(4, i, 0, cur[0][i]); slab_st(5, i, 0, oth[0][i]); }
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                C cc, dd, o0, o1, o2, o3;
-                                bfly_w(slab_ld(4, i, 0), cur[0][i], W128C[2 * i], W128S[2 * i], cc, dd);
-                                bfly_w(slab_ld(0, i, 0), cc, W128C[i], W128S[i], o0, o2);
-                                bfly_w(slab_ld(1, i, 0), dd, -W128S[i], W128C[i], o1, o3);
-                                emit(0, i, 0, o0);
-                                emit(2, i, 0, o1);
-                                emit(4, i, 0, o2);
-                                emit(6, i, 0, o3);
-                                bfly_w(slab_ld(5, i, 0), oth[0][i], W128C[2 * i + 32], W128S[2 * i + 32], cc, dd);
-                                bfly_w(slab_ld(2, i, 0), cc, W128C[i + 16], W128S[i + 16], o0, o2);
-                                bfly_w(slab_ld(3, i, 0), dd, -W128S[i + 16], W128C[i + 16], o1, o3);
-                                emit(1, i, 0, o0);
-                                emit(3, i, 0, o1);
-                                emit(5, i, 0, o2);
-                                emit(7, i, 0, o3);
-                                if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-                            }
+                        for (int i = 0; i < 16; ++i) {
+                            C cc, dd, o0, o1, o2, o3;
+                            bfly_w(slab_ld(4, i, 0), cur[0][i], W128C[2 * i], W128S[2 * i], cc, dd);
+                            bfly_w(slab_ld(0, i, 0), cc, W128C[i], W128S[i], o0, o2);
+                            bfly_w(slab_ld(1, i, 0), dd, -W128S[i], W128C[i], o1, o3);
+                            emit(0, i, 0, o0);
+                            emit(2, i, 0, o1);
+                            emit(4, i, 0, o2);
+                            emit(6, i, 0, o3);
+                            bfly_w(slab_ld(5, i, 0), oth[0][i], W128C[2 * i + 32], W128S[2 * i + 32], cc, dd);
+                            bfly_w(slab_ld(2, i, 0), cc, W128C[i + 16], W128S[i + 16], o0, o2);
+                            bfly_w(slab_ld(3, i, 0), dd, -W128S[i + 16], W128C[i + 16], o1, o3);
+                            emit(1, i, 0, o0);
+                            emit(3, i, 0, o1);
+                            emit(5, i, 0, o2);
+                            emit(7, i, 0, o3);
+                            if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }

@@ -4,6 +4,7 @@
 // the VALU instruction stream of the row, i.e. the issue ceiling bench.py reports as `secondary`.
 #pragma once
 #include "../kernels_duo4096.hpp"
+#include "../kernels_chain.hpp"
 
 namespace caf {
 
@@ -150,6 +151,57 @@ struct SeqIoCut : SeqIo<T> {
         if constexpr (WHAT & 4) asm volatile("" ::"v"(d));
         else B::store(rs, off, d);
     }
+};
+
+// k_chain_rows<T, LOGM, R, NB, MASK>: the chain row kernel with one or several kinds of memory access cut out
+// (CAF_CHAIN_ABL of the measurement library; bench.py's configs[3] ceiling is MASK = 31).  MASK bits: 1 no workgroup
+// barriers (every exchange ends in a wave-local fence), 2 no haystack-spectrum loads, 4 no slab traffic, 8 no needle
+// loads, 16 no surface stores, 128 no LDS chain traffic.  A cut load returns a synthesised value behind the volatile
+// keep() (produced once per use, like the load it stands for); a cut store only keeps its operand alive.
+template <typename T, int MASK>
+struct ChainIoCut {
+    using C = cpx<T>;
+    using P = ChainIo<T>;
+    static constexpr bool wg_barriers = !(MASK & 1);
+    __device__ __forceinline__ static void lds_st(C *Lc, int pos, C x)
+    {
+        if constexpr (MASK & 128) keep(x);
+        else P::lds_st(Lc, pos, x);
+    }
+    __device__ __forceinline__ static C lds_ld(const C *Lc, int pos)
+    {
+        if constexpr (MASK & 128) { C x = C{T(pos), T(1)}; keep(x); return x; }
+        else return P::lds_ld(Lc, pos);
+    }
+    __device__ __forceinline__ static C sample(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int q, int j, int beta)
+    {
+        if constexpr (MASK & 8) { C x = C{T(q + 1 + j), T(beta)}; keep(x); return x; }
+        else return P::sample(rs, voff, soff, q, j, beta);
+    }
+    __device__ __forceinline__ static void spec2(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int k, C &h0, C &h1)
+    {
+        if constexpr (MASK & 2) { h0 = C{T(1), T(k)}; h1 = C{T(k), T(1)}; keep(h0); keep(h1); }
+        else P::spec2(rs, voff, soff, k, h0, h1);
+    }
+    __device__ __forceinline__ static void slab_st(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, C x)
+    {
+        if constexpr (MASK & 4) keep(x);
+        else P::slab_st(rs, voff, soff, x);
+    }
+    __device__ __forceinline__ static C slab_ld(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int arr, int i)
+    {
+        if constexpr (MASK & 4) { C x = C{T(i), T(arr)}; keep(x); return x; }
+        else return P::slab_ld(rs, voff, soff, arr, i);
+    }
+    __device__ __forceinline__ static void surf_st(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, T m)
+    {
+        if constexpr (MASK & 16) asm volatile("" ::"v"(m));
+        else P::surf_st(rs, voff, soff, m);
+    }
+};
+template <typename T, int ABL>
+struct ChainIoFor {
+    using type = ChainIoCut<T, ABL>;
 };
 
 }  // namespace caf
