@@ -31,6 +31,7 @@
 // the environment switches that select them.  The product library contains none of it and reads
 // no environment variable.
 #ifdef CAF_MEASURE
+#include "measure/kernels_lanehalf4096.hpp"  // k_fused_rows: the lane-half row kernel of round 1 (CAF_ROW_KERNEL=1) + its stamped build
 #include "measure/kernels_r8_4096.hpp"
 #include "measure/kernels_big65536.hpp"  // four-step tiled n = 32768 path of round 1 (CAF_CHAIN=0), superseded by the chain path
 #include "measure/kernels_q65536.hpp"
