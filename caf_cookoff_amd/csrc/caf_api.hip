@@ -812,7 +812,7 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
     if (!p->fused) return f64 ? "caf::k_fft_pass<double, 16>" : "caf::k_fft_pass<float, 16>";
     if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 15, caf::SeqIo<double> >" : "caf::k_seq_rows<float, 15, caf::SeqIo<float> >";
     if (p->variant == 2) return f64 ? "caf::k_r8_rows<double, 0>" : "caf::k_r8_rows<float, 0>";
-    if (p->variant == 3) return f64 ? "caf::k_duo_rows<double, 0, caf::DuoIo<double> >" : "caf::k_duo_rows<float, 0, caf::DuoIo<float> >";
+    if (p->variant == 3) return f64 ? "caf::k_duo_rows<double, caf::DuoIo<double> >" : "caf::k_duo_rows<float, caf::DuoIo<float> >";
     return f64 ? "caf::k_fused_rows<double, false>" : "caf::k_fused_rows<float, false>";
 }
 
@@ -949,9 +949,9 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
         else
             k_fused_rows<T, false><<<gf, F_THREADS, 0, c->stream>>>(a);
     } else if (p->variant == 3 && store_mode == 3) {
-        k_duo_rows<T, 3><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
+        k_duo_rows<T, DuoIoNoStore<T>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
     } else if (p->variant == 3 && store_mode == 33) {  // VALU only: the product body over the null memory policy
-        k_duo_rows<T, 0, DuoIoNull<T>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
+        k_duo_rows<T, DuoIoNull<T>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
     } else if (p->variant == 0 && store_mode != 0) {
         switch (store_mode) {  // measurement policies over the product kernel body (WRONG results, timing only), and PF = 0
         case 3: k_seq_rows<T, 15, SeqIoCut<T, 4>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;   // no surface stores
@@ -966,7 +966,7 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     } else
 #endif
     if (p->variant == 3)
-        k_duo_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex64 product kernel
+        k_duo_rows<T><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex64 product kernel
     else
         k_seq_rows<T><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex128 product kernel
     KCHK();

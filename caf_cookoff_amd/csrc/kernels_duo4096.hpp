@@ -92,7 +92,7 @@ struct DuoIo {
     }
 };
 
-template <typename T, int STORE = 0, typename IO = DuoIo<T>>
+template <typename T, typename IO = DuoIo<T>>
 __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_duo_rows(const FusedArgs<T> A,
                                                                              const cpx<T> *__restrict__ phasor)
 {
@@ -253,12 +253,8 @@ __global__ __launch_bounds__(S_THREADS, seq_waves_per_simd<T>()) void k_duo_rows
             pair_xor1(mlo[2 * j], mlo[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dlo);
             pair_xor1(mhi[2 * j], mhi[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dhi);
             const int m = mpair + 256 * (2 * j + (odd ? 1 : 0));
-            if constexpr (STORE != 3) {
-                io.store(rs, (unsigned)(m * sizeof(T)), dlo);
-                io.store(rs, (unsigned)((m + F_N) * sizeof(T)), dhi);
-            } else {
-                asm volatile("" ::"v"(dlo), "v"(dhi));
-            }
+            io.store(rs, (unsigned)(m * sizeof(T)), dlo);
+            io.store(rs, (unsigned)((m + F_N) * sizeof(T)), dhi);
         }
         T bv = bv_lo;
         uint32_t bi = bv_lo > T(0) ? (uint32_t)(L.t + 256 * bi_lo) : 0u;

@@ -18,7 +18,7 @@ __device__ __forceinline__ void opaque(cpx<T> &x)
     asm("" : "+v"(x.x), "+v"(x.y));
 }
 
-// k_duo_rows<T, 0, DuoIoNull<T>>: no LDS traffic, no barriers, no global loads, no surface stores.  An LDS exchange
+// k_duo_rows<T, DuoIoNull<T>>: no LDS traffic, no barriers, no global loads, no surface stores.  An LDS exchange
 // becomes a hand-over through sixteen registers of the policy object (identity "permutation"): every value a stage
 // produces still feeds the next stage, so nothing is dead and no scheduling fence is needed -- the compiler keeps the
 // product's arithmetic and is as free to schedule it as in the product.
@@ -81,6 +81,16 @@ struct DuoIoNull {
     __device__ __forceinline__ void store(const __amdgpu_buffer_rsrc_t, unsigned, V d) const
     {
         asm volatile("" ::"v"(d));  // the row's results must stay live
+    }
+};
+
+// k_duo_rows<T, DuoIoNoStore<T>>: the product row without its surface stores (CAF_STORE_MODE=3 with CAF_ROW_KERNEL=3)
+template <typename T>
+struct DuoIoNoStore : DuoIo<T> {
+    template <typename V>
+    __device__ __forceinline__ void store(const __amdgpu_buffer_rsrc_t, unsigned, V d) const
+    {
+        asm volatile("" ::"v"(d));
     }
 };
 

@@ -64,6 +64,6 @@ def test_algorithmic_bytes_match_survey_8d():
     assert big == 2 * 262_144 + 4096 * 65536 * 4 + 4096 * 12
     assert len(bench.kernel_source_hash()) == 16
     # per-kernel: the streaming header is not part of the batched row kernels' sources
-    h = {k: bench.kernel_source_hash(k) for k in ("caf::k_seq_rows<double, 15, caf::SeqIo<double> >", "caf::k_duo_rows<float, 0, caf::DuoIo<float> >",
+    h = {k: bench.kernel_source_hash(k) for k in ("caf::k_seq_rows<double, 15, caf::SeqIo<double> >", "caf::k_duo_rows<float, caf::DuoIo<float> >",
                                                    "caf::k_chain_rows<float, 14, 4, 1, 0>", "")}
     assert len(set(h.values())) == 4
