@@ -88,3 +88,35 @@ def test_multi_stream_share_is_a_round_robin_partition(count, nworkers):
         caf.multi_stream_share(10, 0, 0)
     with pytest.raises(caf.CafError):
         caf.multi_stream_share(10, 2, 2)
+
+
+def test_small_row_lds_geometry_is_conflict_free_under_the_bank_model():
+    """The exchange and staging strides of k_small_rows (kernels_small.hpp: element e at e + (e >> 4), rows
+    L + L/16 apart, |.|^2 staging rows of ROWT reals) were chosen with tools/lds_banks_small.py, a model of the LDS
+    bank rules of MI355X_MICROARCH.md; the counters agree (profiles/r03_small_rows_lds.txt).  Keep model and
+    geometry in step: conflict-free exchanges for L = 32 ... 256, the known 128 extra cycles of the second exchange
+    at L = 512 / 1024, conflict-free staging from L = 32 on."""
+    import importlib.util
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("lds_banks_small", root / "tools" / "lds_banks_small.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    src = (root / "caf_cookoff_amd" / "csrc" / "kernels_small.hpp").read_text()
+    assert re.search(r"static constexpr int ROWX = L \+ L / 16;", src)
+    assert "return e + (e >> 4);" in src
+    assert re.search(r"ROWT = L >= 256 \? L : L \+ \(sizeof\(T\) == 8 \? L / 16 : \(L >= 32 \? L / 32 : 1\)\);", src)
+    for esz in (16, 8):
+        for logl in range(5, 11):
+            L = 1 << logl
+            cyc, floor, rowx = m.exchange(logl, esz, 1)          # extra = 1: ROWX = P(L - 1) + 1 + 1 = L + L/16
+            assert rowx == L + L // 16
+            if L <= 256:
+                assert cyc == floor, (L, esz, cyc, floor)
+            else:
+                assert cyc - floor == (128 if esz == 16 else 64), (L, esz, cyc, floor)
+            tsz = esz // 2
+            pad_t = 0 if L >= 256 else (L // 16 if tsz == 8 else max(1, L // 32))
+            scyc, sfloor, _ = m.staging(logl, tsz, pad_t)
+            assert scyc == sfloor, (L, tsz, scyc, sfloor)
