@@ -205,7 +205,10 @@ int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, 
  * caf_peak records out) -- no copy-engine nodes.  While slot k computes, the caller fills slot
  * k+1's pinned buffers and submits it: its input transfer overlaps slot k's kernels.  Three or
  * four slots sustain the most single-surface replays per second on MI355X (the
- * slot streams are probed at creation so that they sit on separate hardware queues).  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
+ * slot streams are probed at creation so that they sit on separate hardware queues), but that rate
+ * depends on how the runtime arbitrates the slot streams' hardware queues; batch = 8 with four slots
+ * is the fastest form measured and the one that keeps its rate from creation to creation
+ * (profiles/r03_stream/form_stability.txt).  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
  * only (tau, f) + per-row peaks come back, as SURVEY.md section 8d prescribes.
  * Plans whose row kernel keeps its intermediate data on-chip ("fused4096", "chain", "small") give
  * every slot private device state, so slots execute concurrently.  Plans on the
