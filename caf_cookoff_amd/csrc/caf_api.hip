@@ -63,6 +63,15 @@ static int fail(int code, const char *fmt, ...)
 
 #define KCHK() HIPCHK(hipGetLastError())
 
+// No C++ exception leaves the library (include/caf_hip.h: "never unwind across the boundary"): every int-returning
+// entry point runs inside this guard (std::bad_alloc of a container -> CAF_ERR_NOMEM).
+#define CAF_GUARD_BEGIN try {
+#define CAF_GUARD_END                                                                                 \
+    }                                                                                                 \
+    catch (const std::bad_alloc &) { return fail(CAF_ERR_NOMEM, "%s: out of host memory", __func__); } \
+    catch (const std::exception &e) { return fail(CAF_ERR_STATE, "%s: C++ exception: %s", __func__, e.what()); } \
+    catch (...) { return fail(CAF_ERR_STATE, "%s: unknown C++ exception", __func__); }
+
 #ifdef CAF_MEASURE
 static long measure_env(const char *name, long dflt)
 {
@@ -223,9 +232,11 @@ extern "C" const char *caf_last_error_string(void) { return g_err; }
 
 extern "C" int caf_device_count(void)
 {
+    CAF_GUARD_BEGIN
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+    CAF_GUARD_END
 }
 
 template <typename T>
@@ -290,6 +301,7 @@ static int run_fft(caf_ctx *c, cpx<T> *x, cpx<T> *y, const cpx<T> *tw, size_t L,
 // ------------------------------------------------------------------ context --
 extern "C" int caf_ctx_create(int device_id, caf_ctx **out)
 {
+    CAF_GUARD_BEGIN
     if (!out) return fail(CAF_ERR_BAD_ARG, "caf_ctx_create: out is NULL");
     *out = nullptr;
     int ndev = 0;
@@ -312,6 +324,7 @@ extern "C" int caf_ctx_create(int device_id, caf_ctx **out)
     c->stream = c->own_stream;
     *out = c;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_plan_destroy(caf_plan *p);
@@ -319,6 +332,7 @@ static void host_slot_free(HostSlot *s);
 
 extern "C" int caf_ctx_destroy(caf_ctx *c)
 {
+    CAF_GUARD_BEGIN
     if (!c) return CAF_OK;
     for (caf_plan *p : c->plans)
         if (p->live_streams)
@@ -351,35 +365,43 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_ctx_set_stream(caf_ctx *c, void *hip_stream)
 {
+    CAF_GUARD_BEGIN
     if (!c) return fail(CAF_ERR_BAD_ARG, "ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->stream = (hipStream_t)hip_stream;  // NULL == the null stream
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_ctx_reset_stream(caf_ctx *c)
 {
+    CAF_GUARD_BEGIN
     if (!c) return fail(CAF_ERR_BAD_ARG, "ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->stream = c->own_stream;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_ctx_synchronize(caf_ctx *c)
 {
+    CAF_GUARD_BEGIN
     if (!c) return fail(CAF_ERR_BAD_ARG, "ctx is NULL");
     HIPCHK(hipStreamSynchronize(c->stream));
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_ctx_device_info(caf_ctx *c, int *cu_count, char *name_buf, size_t name_cap)
 {
+    CAF_GUARD_BEGIN
     if (!c) return fail(CAF_ERR_BAD_ARG, "ctx is NULL");
     if (cu_count) *cu_count = c->cu_count;
     if (name_buf && name_cap) {
@@ -387,6 +409,7 @@ extern "C" int caf_ctx_device_info(caf_ctx *c, int *cu_count, char *name_buf, si
         name_buf[name_cap - 1] = 0;
     }
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 // --------------------------------------------------------- apply_freq_shift --
@@ -419,12 +442,16 @@ static int apply_shift_impl(caf_ctx *c, const T *in, size_t n, double f, uint32_
 extern "C" int caf_apply_freq_shift_c128(caf_ctx *c, const double *in, size_t n, double f, uint32_t fs,
                                          double *out)
 {
+    CAF_GUARD_BEGIN
     return apply_shift_impl<double>(c, in, n, f, fs, out);
+    CAF_GUARD_END
 }
 extern "C" int caf_apply_freq_shift_c64(caf_ctx *c, const float *in, size_t n, double f, uint32_t fs,
                                         float *out)
 {
+    CAF_GUARD_BEGIN
     return apply_shift_impl<float>(c, in, n, f, fs, out);
+    CAF_GUARD_END
 }
 
 // -------------------------------------------------------------------- xcor --
@@ -520,11 +547,15 @@ static int xcor_impl(caf_ctx *c, const T *a, const T *b, size_t n, T *out, int d
 
 extern "C" int caf_xcor_c128(caf_ctx *c, const double *a, const double *b, size_t n, double *out)
 {
+    CAF_GUARD_BEGIN
     return xcor_impl<double>(c, a, b, n, out, CAF_C128);
+    CAF_GUARD_END
 }
 extern "C" int caf_xcor_c64(caf_ctx *c, const float *a, const float *b, size_t n, float *out)
 {
+    CAF_GUARD_BEGIN
     return xcor_impl<float>(c, a, b, n, out, CAF_C64);
+    CAF_GUARD_END
 }
 
 template <typename T>
@@ -698,6 +729,7 @@ static int plan_build_tables(caf_plan *p)
 extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, size_t nfreq, uint32_t fs,
                                int dtype, size_t row_begin, size_t row_end, caf_plan **out)
 {
+    CAF_GUARD_BEGIN
     if (!c || !out) return fail(CAF_ERR_BAD_ARG, "plan_create: NULL argument");
     *out = nullptr;
     if (!freqs_hz && nfreq) return fail(CAF_ERR_BAD_ARG, "plan_create: freqs_hz is NULL");
@@ -758,10 +790,12 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     c->plans.push_back(p);
     *out = p;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_plan_destroy(caf_plan *p)
 {
+    CAF_GUARD_BEGIN
     if (!p) return CAF_OK;
     // the captured graphs of a caf_stream hold raw pointers into this plan's tables and workspaces
     if (p->live_streams)
@@ -781,6 +815,7 @@ extern "C" int caf_plan_destroy(caf_plan *p)
     for (auto ev : p->ev) (void)hipEventDestroy(ev);
     delete p;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" const char *caf_plan_path(const caf_plan *p)
@@ -830,14 +865,17 @@ static int timing_mark(caf_plan *p)
 
 extern "C" int caf_plan_timing_begin(caf_plan *p)
 {
+    CAF_GUARD_BEGIN
     if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
     p->timing = true;
     p->ev_used = 0;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_plan_timing_end(caf_plan *p, double *ms_total, uint64_t *launches)
 {
+    CAF_GUARD_BEGIN
     if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
     HIPCHK(hipSetDevice(p->ctx->device));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
@@ -852,6 +890,7 @@ extern "C" int caf_plan_timing_end(caf_plan *p, double *ms_total, uint64_t *laun
     p->timing = false;
     p->ev_used = 0;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 #ifdef CAF_MEASURE
@@ -861,6 +900,7 @@ extern "C" int caf_plan_timing_end(caf_plan *p, double *ms_total, uint64_t *laun
 // variants have no DIAG build (the stamped form of k_seq_rows went with round 3's clean-up of that kernel).
 extern "C" int caf_debug_set_stamps(caf_plan *p, void *d_buf, size_t len_u64)
 {
+    CAF_GUARD_BEGIN
     if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
     if (d_buf) {
         if (!p->fused || p->variant != 1)
@@ -872,6 +912,7 @@ extern "C" int caf_debug_set_stamps(caf_plan *p, void *d_buf, size_t len_u64)
     p->dbg = (unsigned long long *)d_buf;
     p->dbg_len = d_buf ? len_u64 : 0;
     return CAF_OK;
+    CAF_GUARD_END
 }
 #endif
 
@@ -1408,6 +1449,7 @@ static int surface_dev_generic(caf_plan *p, const void *d_needle, const void *d_
 extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch,
                                void *d_surface, uint64_t *d_ridx, void *d_rval, caf_peak *d_peak)
 {
+    CAF_GUARD_BEGIN
     if (!p || !d_needle || !d_hay || !d_peak) return fail(CAF_ERR_BAD_ARG, "caf_surface_dev: NULL argument");
     if (p->rows && (!d_ridx || !d_rval)) return fail(CAF_ERR_BAD_ARG, "caf_surface_dev: row outputs are NULL");
     if (batch == 0) return CAF_OK;
@@ -1447,6 +1489,7 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
                                                               (int64_t)p->row_begin, d_peak, p->stage_out);
     KCHK();
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 // ----------------------------------------------------------- surface (host) --
@@ -1703,19 +1746,24 @@ extern "C" int caf_surface_c128(caf_ctx *c, const double *needle, const double *
                                 const double *freqs, size_t nfreq, uint32_t fs, double *surface,
                                 uint64_t *row_idx, double *row_val, caf_peak *peak)
 {
+    CAF_GUARD_BEGIN
     return surface_host_impl<double>(c, needle, hay, n, freqs, nfreq, fs, surface, row_idx, row_val, peak, CAF_C128);
+    CAF_GUARD_END
 }
 
 extern "C" int caf_surface_c64(caf_ctx *c, const float *needle, const float *hay, size_t n, const double *freqs,
                                size_t nfreq, uint32_t fs, float *surface, uint64_t *row_idx, float *row_val,
                                caf_peak *peak)
 {
+    CAF_GUARD_BEGIN
     return surface_host_impl<float>(c, needle, hay, n, freqs, nfreq, fs, surface, row_idx, row_val, peak, CAF_C64);
+    CAF_GUARD_END
 }
 
 // ---- caller memory the kernels may write in place ------------------------------------------------------
 extern "C" int caf_host_alloc(caf_ctx *c, size_t bytes, void **out)
 {
+    CAF_GUARD_BEGIN
     if (!c || !out || !bytes) return fail(CAF_ERR_BAD_ARG, "caf_host_alloc: NULL argument or zero size");
     *out = nullptr;
     HIPCHK(hipSetDevice(c->device));
@@ -1727,10 +1775,12 @@ extern "C" int caf_host_alloc(caf_ctx *c, size_t bytes, void **out)
     c->host_ranges[(char *)h] = HostRange{bytes, (char *)m, true};
     *out = h;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_host_register(caf_ctx *c, void *ptr, size_t bytes)
 {
+    CAF_GUARD_BEGIN
     if (!c || !ptr || !bytes) return fail(CAF_ERR_BAD_ARG, "caf_host_register: NULL argument or zero size");
     HIPCHK(hipSetDevice(c->device));
     if (c->host_ranges.count((char *)ptr)) return fail(CAF_ERR_STATE, "caf_host_register: %p is already registered", ptr);
@@ -1740,6 +1790,7 @@ extern "C" int caf_host_register(caf_ctx *c, void *ptr, size_t bytes)
     if (e != hipSuccess) { (void)hipHostUnregister(ptr); return fail(CAF_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
     c->host_ranges[(char *)ptr] = HostRange{bytes, (char *)m, false};
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 static int host_range_drop(caf_ctx *c, void *ptr, bool owned, const char *who)
@@ -1763,6 +1814,7 @@ extern "C" int caf_host_unregister(caf_ctx *c, void *ptr) { return host_range_dr
 extern "C" int caf_find_peak(caf_ctx *c, const double *freqs, const uint64_t *row_idx, const double *row_val,
                              size_t nfreq, caf_peak *peak)
 {
+    CAF_GUARD_BEGIN
     if (!c || !peak) return fail(CAF_ERR_BAD_ARG, "caf_find_peak: NULL argument");
     if (nfreq && (!freqs || !row_idx || !row_val)) return fail(CAF_ERR_BAD_ARG, "caf_find_peak: NULL rows");
     if (nfreq > 0x7fffffffu) return fail(CAF_ERR_BAD_ARG, "caf_find_peak: too many rows");
@@ -1783,6 +1835,7 @@ extern "C" int caf_find_peak(caf_ctx *c, const double *freqs, const uint64_t *ro
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(peak, h + 3 * col, sizeof(caf_peak));
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 // ------------------------------------------------------------------- views --
@@ -1820,6 +1873,7 @@ static int view_impl(caf_ctx *c, const T *surface, size_t rows, size_t n, int vi
 
 extern "C" int caf_surface_view(caf_ctx *c, int dtype, const void *surface, size_t rows, size_t n, int view, void *out)
 {
+    CAF_GUARD_BEGIN
     if (!c || !out || (!surface && rows)) return fail(CAF_ERR_BAD_ARG, "caf_surface_view: NULL argument");
     if (view != CAF_VIEW_GO && view != CAF_VIEW_PYTHON) return fail(CAF_ERR_BAD_ARG, "caf_surface_view: bad view %d", view);
     if (dtype != CAF_C128 && dtype != CAF_C64) return fail(CAF_ERR_BAD_ARG, "caf_surface_view: bad dtype %d", dtype);
@@ -1828,6 +1882,7 @@ extern "C" int caf_surface_view(caf_ctx *c, int dtype, const void *surface, size
     HIPCHK(hipSetDevice(c->device));
     return dtype == CAF_C128 ? view_impl<double>(c, (const double *)surface, rows, n, view, (double *)out)
                              : view_impl<float>(c, (const float *)surface, rows, n, view, (float *)out);
+    CAF_GUARD_END
 }
 
 // --------------------------------------------------------------- streaming --
@@ -1911,6 +1966,7 @@ static bool streams_overlap(caf_ctx *c, hipStream_t a, hipStream_t b)
 extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int want_surface, unsigned flags,
                                     caf_stream **out)
 {
+    CAF_GUARD_BEGIN
     if (!p || !out) return fail(CAF_ERR_BAD_ARG, "caf_stream_create: NULL argument");
     *out = nullptr;
     if (batch == 0 || nslots < 2 || nslots > 16) return fail(CAF_ERR_BAD_ARG, "caf_stream_create: batch >= 1, 2 <= nslots <= 16");
@@ -2160,19 +2216,24 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     ++p->live_streams;  // caf_plan_destroy / caf_ctx_destroy refuse while the graphs hold the plan's buffers
     *out = st;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_stream_create(caf_plan *p, size_t batch, int nslots, int want_surface, caf_stream **out)
 {
+    CAF_GUARD_BEGIN
     return caf_stream_create_ex(p, batch, nslots, want_surface, 0u, out);
+    CAF_GUARD_END
 }
 
 extern "C" int caf_stream_destroy(caf_stream *st)
 {
+    CAF_GUARD_BEGIN
     if (!st) return CAF_OK;
     (void)hipSetDevice(st->plan->ctx->device);
     stream_free(st);
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 static int slot_ok(caf_stream *st, int slot)
@@ -2184,21 +2245,25 @@ static int slot_ok(caf_stream *st, int slot)
 
 extern "C" int caf_stream_host_buffers(caf_stream *st, int slot, void **needle, void **haystack)
 {
+    CAF_GUARD_BEGIN
     int rc = slot_ok(st, slot);
     if (rc) return rc;
     if (needle) *needle = st->slots[slot].h_needle;
     if (haystack) *haystack = st->slots[slot].h_hay;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_stream_submit(caf_stream *st, int slot)
 {
+    CAF_GUARD_BEGIN
     int rc = slot_ok(st, slot);
     if (rc) return rc;
     HIPCHK(hipSetDevice(st->plan->ctx->device));
     HIPCHK(hipGraphLaunch(st->slots[slot].exec, st->slots[slot].stream));
     ++st->slots[slot].submits;  // counted only once the replay is really enqueued (caf_stream_wait polls for this number)
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 // Completion of a slot whose surfaces are single launches: each writes its launch count to pinned memory
@@ -2213,6 +2278,7 @@ static int slot_wait(StreamSlot &s, size_t batch)
 
 extern "C" int caf_stream_wait(caf_stream *st, int slot, caf_peak *peaks, uint64_t *row_idx, void *row_val)
 {
+    CAF_GUARD_BEGIN
     int rc = slot_ok(st, slot);
     if (rc) return rc;
     StreamSlot &s = st->slots[slot];
@@ -2231,6 +2297,7 @@ extern "C" int caf_stream_wait(caf_stream *st, int slot, caf_peak *peaks, uint64
     if (row_idx && rows) memcpy(row_idx, s.h_ridx, st->batch * rows * sizeof(uint64_t));
     if (row_val && rows) memcpy(row_val, s.h_rval, st->batch * rows * real_size(st->plan->dtype));
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 // The whole streaming loop in native code (BASELINE configs[4]: `count` host-resident pairs, one after the
@@ -2291,17 +2358,21 @@ static int stream_run_strided(caf_stream *st, const void *needles, const void *h
 
 extern "C" int caf_stream_run_stats(caf_stream *st, double *seconds4)
 {
+    CAF_GUARD_BEGIN
     if (!st || !seconds4) return fail(CAF_ERR_BAD_ARG, "caf_stream_run_stats: NULL argument");
     for (int i = 0; i < 4; ++i) seconds4[i] = st->run_stats[i];
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_stream_run(caf_stream *st, const void *needles, const void *haystacks, size_t count, caf_peak *peaks,
                               uint64_t *row_idx, void *row_val)
 {
+    CAF_GUARD_BEGIN
     if (!st) return fail(CAF_ERR_BAD_ARG, "stream is NULL");
     if (count && (!needles || !haystacks || !peaks)) return fail(CAF_ERR_BAD_ARG, "caf_stream_run: NULL argument");
     return stream_run_strided(st, needles, haystacks, 0, 1, count, peaks, row_idx, row_val);
+    CAF_GUARD_END
 }
 
 // ------------------------------------------------------- surface-parallel multi-GPU --
@@ -2312,12 +2383,14 @@ extern "C" int caf_stream_run(caf_stream *st, const void *needles, const void *h
 // collective at all: a surface's (tau, f) is complete on the device that computed it.
 extern "C" int caf_multi_stream_share(size_t count, int nworkers, int worker, size_t *first, size_t *stride, size_t *items)
 {
+    CAF_GUARD_BEGIN
     if (nworkers <= 0 || worker < 0 || worker >= nworkers) return fail(CAF_ERR_BAD_ARG, "caf_multi_stream_share: worker %d of %d", worker, nworkers);
     const size_t w = (size_t)worker, nw = (size_t)nworkers;
     if (first) *first = w;
     if (stride) *stride = nw;
     if (items) *items = count > w ? (count - w + nw - 1) / nw : 0;  // pairs w, w + nw, w + 2 nw, ... < count
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 struct MultiWorker {
@@ -2334,6 +2407,7 @@ struct caf_multi_stream {
 
 extern "C" int caf_multi_stream_destroy(caf_multi_stream *ms)
 {
+    CAF_GUARD_BEGIN
     if (!ms) return CAF_OK;
     for (auto &w : ms->workers) {
         if (w.stream) caf_stream_destroy(w.stream);
@@ -2342,11 +2416,13 @@ extern "C" int caf_multi_stream_destroy(caf_multi_stream *ms)
     }
     delete ms;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_multi_stream_create(const int *device_ids, int ndev, size_t n, const double *freqs_hz, size_t nfreq,
                                        uint32_t fs, int dtype, int nslots, caf_multi_stream **out)
 {
+    CAF_GUARD_BEGIN
     if (!out || !device_ids || ndev <= 0 || ndev > 64) return fail(CAF_ERR_BAD_ARG, "caf_multi_stream_create: bad device list");
     *out = nullptr;
     caf_multi_stream *ms = new (std::nothrow) caf_multi_stream;
@@ -2365,6 +2441,7 @@ extern "C" int caf_multi_stream_create(const int *device_ids, int ndev, size_t n
     }
     *out = ms;
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" int caf_multi_stream_devices(const caf_multi_stream *ms) { return ms ? (int)ms->workers.size() : 0; }
@@ -2372,6 +2449,7 @@ extern "C" int caf_multi_stream_devices(const caf_multi_stream *ms) { return ms 
 extern "C" int caf_multi_stream_run(caf_multi_stream *ms, const void *needles, const void *haystacks, size_t count,
                                     caf_peak *peaks, uint64_t *row_idx, void *row_val)
 {
+    CAF_GUARD_BEGIN
     if (!ms) return fail(CAF_ERR_BAD_ARG, "multi stream is NULL");
     if (count && (!needles || !haystacks || !peaks)) return fail(CAF_ERR_BAD_ARG, "caf_multi_stream_run: NULL argument");
     const int nw = (int)ms->workers.size();
@@ -2383,10 +2461,14 @@ extern "C" int caf_multi_stream_run(caf_multi_stream *ms, const void *needles, c
         w->err.clear();
         try {  // nothing may unwind across the C boundary: a thread that cannot be started fails the call instead
             threads.emplace_back([=] {  // one host thread per device: the C ABI's contexts are single-threaded objects
-                size_t first = 0, stride = 1, items = 0;
-                caf_multi_stream_share(count, nw, i, &first, &stride, &items);
-                w->rc = stream_run_strided(w->stream, needles, haystacks, first, stride, items, peaks, row_idx, row_val);
-                if (w->rc) w->err = g_err;  // thread-local message of the worker thread
+                try {  // (an exception escaping a thread function would terminate the process)
+                    size_t first = 0, stride = 1, items = 0;
+                    caf_multi_stream_share(count, nw, i, &first, &stride, &items);
+                    w->rc = stream_run_strided(w->stream, needles, haystacks, first, stride, items, peaks, row_idx, row_val);
+                    if (w->rc) w->err = g_err;  // thread-local message of the worker thread
+                } catch (...) {
+                    w->rc = CAF_ERR_NOMEM;
+                }
             });
         } catch (...) {
             spawn_failed = true;
@@ -2400,6 +2482,7 @@ extern "C" int caf_multi_stream_run(caf_multi_stream *ms, const void *needles, c
             return fail(ms->workers[i].rc, "caf_multi_stream_run: worker %d (device %d): %s", i, ms->workers[i].device,
                         ms->workers[i].err.c_str());
     return CAF_OK;
+    CAF_GUARD_END
 }
 
 extern "C" void *caf_stream_surface(caf_stream *st, int slot)
