@@ -15,6 +15,20 @@ DATA = GOLDEN / "data"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _install_abort_trace()
+
+
+def _install_abort_trace():
+    """tests/cpp/abort_trace.c: if a native library under the tests calls abort(), print the native stack before
+    faulthandler's Python stacks.  Installed after pytest's own faulthandler set-up, so this
+    handler runs first and then hands over to it.  Missing helper (not built): nothing happens."""
+    import ctypes
+    so = ROOT / "tests" / "cpp" / "abort_trace.so"
+    if so.exists():
+        try:
+            ctypes.CDLL(str(so)).abort_trace_install()
+        except OSError:
+            pass
 
 
 @pytest.fixture(scope="session")
