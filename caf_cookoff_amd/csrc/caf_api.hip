@@ -2,6 +2,7 @@
 // No torch types, no CPU fallback: every entry point fails loudly without a GPU.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -26,18 +27,6 @@
 #include "kernels_small.hpp"
 #include "kernels_xcor.hpp"
 #include "kernels_generic.hpp"
-// Measurement build (-DCAF_MEASURE -> libcaf_hip_measure.so, used by tools/ and the variant
-// tests only): rejected kernel variants, ablation instantiations that produce WRONG results and
-// the environment switches that select them.  The product library contains none of it and reads
-// no environment variable.
-#ifdef CAF_MEASURE
-#include "measure/kernels_lanehalf4096.hpp"  // k_fused_rows: the lane-half row kernel of round 1 (CAF_ROW_KERNEL=1) + its stamped build
-#include "measure/kernels_r8_4096.hpp"
-#include "measure/kernels_big65536.hpp"  // four-step tiled n = 32768 path of round 1 (CAF_CHAIN=0), superseded by the chain path
-#include "measure/kernels_q65536.hpp"
-#include "measure/kernels_ablate.hpp"     // arithmetic-only memory policies (issue ceilings; wrong results)
-#include "measure/kernels_r32.hpp"        // configs[3] with 32 points per thread (CAF_R32=1): VERDICT r02 item 4, measured and rejected or promoted
-#endif
 
 using namespace caf;
 
@@ -72,44 +61,104 @@ static int fail(int code, const char *fmt, ...)
     catch (const std::exception &e) { return fail(CAF_ERR_STATE, "%s: C++ exception: %s", __func__, e.what()); } \
     catch (...) { return fail(CAF_ERR_STATE, "%s: unknown C++ exception", __func__); }
 
-#ifdef CAF_MEASURE
-static long measure_env(const char *name, long dflt)
-{
-    const char *v = getenv(name);
-    return v ? atol(v) : dflt;
-}
-#else
-static constexpr long measure_env(const char *, long dflt) { return dflt; }
-#endif
 
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 static size_t elem_size(int dtype) { return dtype == CAF_C128 ? 16 : 8; }
 static size_t real_size(int dtype) { return dtype == CAF_C128 ? 8 : 4; }
 
+// -------------------------------------------------------------- allocations --
+// Every device / pinned allocation of the library goes through these four functions.  With red zones switched on
+// (caf_debug_guard_bands, a process-wide debug setting; GPU AddressSanitizer does not exist on this hardware pool) an
+// allocation of `bytes` becomes [guard | bytes | guard] with both guards filled with 0xA5, and
+// caf_debug_check_guards() verifies every live allocation's guards: a kernel that stores outside a table, a slab, a
+// staging buffer or a surface is caught after the fact.  Off (the default) they are hipMalloc / hipHostMalloc.
+struct GuardRec {
+    char *base = nullptr;  // what the runtime returned
+    size_t bytes = 0, guard = 0;
+    int device = 0;
+    bool pinned = false;
+    int line = 0;  // allocation site in this file
+};
+static std::mutex g_guard_mu;
+static std::map<void *, GuardRec> g_guarded;  // user pointer -> record
+static std::atomic<size_t> g_guard_bytes{0};
+static std::atomic<size_t> g_guard_live{0};
+static constexpr unsigned char GUARD_FILL = 0xA5;
+
+static hipError_t raw_pinned_alloc(void **p, size_t bytes)
+{
+    // explicitly coherent (fine-grained) and mapped, not "whatever the runtime's default is": the kernels read and
+    // write this memory in place and the host polls it; portable: every device of a caf_multi_* object may address it
+    return hipHostMalloc(p, bytes, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable);
+}
+
+static hipError_t guarded_alloc(void **p, size_t bytes, bool pinned, int line)
+{
+    const size_t g = g_guard_bytes.load(std::memory_order_relaxed);
+    if (g == 0) return pinned ? raw_pinned_alloc(p, bytes) : hipMalloc(p, bytes);
+    char *base = nullptr;
+    hipError_t e = pinned ? raw_pinned_alloc((void **)&base, bytes + 2 * g) : hipMalloc((void **)&base, bytes + 2 * g);
+    if (e != hipSuccess) return e;
+    if (pinned) {
+        memset(base, GUARD_FILL, g);
+        memset(base + g + bytes, GUARD_FILL, g);
+    } else {
+        e = hipMemset(base, GUARD_FILL, g);
+        if (e == hipSuccess) e = hipMemset(base + g + bytes, GUARD_FILL, g);
+        if (e == hipSuccess) e = hipDeviceSynchronize();  // the library's streams do not wait for the null stream
+        if (e != hipSuccess) { (void)hipFree(base); return e; }
+    }
+    GuardRec r;
+    r.base = base; r.bytes = bytes; r.guard = g; r.pinned = pinned; r.line = line;
+    (void)hipGetDevice(&r.device);
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        g_guarded[base + g] = r;
+    }
+    g_guard_live.fetch_add(1);
+    *p = base + g;
+    return hipSuccess;
+}
+
+static hipError_t guarded_free(void *p, bool pinned)
+{
+    if (!p) return hipSuccess;
+    if (g_guard_live.load() != 0) {
+        void *base = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_guard_mu);
+            auto it = g_guarded.find(p);
+            if (it != g_guarded.end()) { base = it->second.base; g_guarded.erase(it); }
+        }
+        if (base) { g_guard_live.fetch_sub(1); p = base; }
+    }
+    return pinned ? hipHostFree(p) : hipFree(p);
+}
+
+#define dev_alloc(pp, bytes) guarded_alloc((void **)(pp), (bytes), false, __LINE__)
+#define pinned_alloc(pp, bytes) guarded_alloc((void **)(pp), (bytes), true, __LINE__)
+static hipError_t dev_free(void *p) { return guarded_free(p, false); }
+static hipError_t pin_free(void *p) { return guarded_free(p, true); }
+
 // ----------------------------------------------------------------- structs --
+struct MeasureCtx;   // measurement build only: measure/dispatch.inc
+struct MeasurePlan;
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return CAF_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (p) { (void)dev_free(p); p = nullptr; cap = 0; }
         if (bytes == 0) return CAF_OK;
-        hipError_t e = hipMalloc(&p, bytes);
+        hipError_t e = dev_alloc(&p, bytes);
         if (e != hipSuccess) { p = nullptr; return fail(CAF_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
         cap = bytes;
         return CAF_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)dev_free(p); p = nullptr; cap = 0; }
 };
-
-// Pinned host memory for everything a kernel and the host both touch (staging buffers, result words,
-// sequence / status words): explicitly coherent (fine-grained) and mapped, not "whatever the runtime's
-// default is" -- the kernels read and write it in place and the host polls it.
-static hipError_t pinned_alloc(void **p, size_t bytes)
-{
-    return hipHostMalloc(p, bytes, hipHostMallocCoherent | hipHostMallocMapped);
-}
 
 // a pinned staging buffer of the host-pointer entry points and its device mapping (grows, never shrinks)
 struct PinBuf {
@@ -122,11 +171,11 @@ struct PinBuf {
         hipError_t e = pinned_alloc(&h, bytes);
         if (e != hipSuccess) { h = nullptr; return fail(CAF_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
         e = hipHostGetDevicePointer(&m, h, 0);
-        if (e != hipSuccess) { (void)hipHostFree(h); h = nullptr; return fail(CAF_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)pin_free(h); h = nullptr; return fail(CAF_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
         cap = bytes;
         return CAF_OK;
     }
-    void release() { if (h) (void)hipHostFree(h); h = m = nullptr; cap = 0; }
+    void release() { if (h) (void)pin_free(h); h = m = nullptr; cap = 0; }
 };
 
 // One cached (n, freq list, fs, dtype) of the host-pointer caf_surface_* entry points: its plan (what
@@ -160,9 +209,6 @@ struct caf_ctx {
     // row-independent fused tables per dtype
     void *tw4096[2] = {nullptr, nullptr};
     void *th[2] = {nullptr, nullptr};
-    void *bigw256[2] = {nullptr, nullptr};  // tiled65536 path tables
-    void *bigwL[2] = {nullptr, nullptr};
-    void *qoutw[2] = {nullptr, nullptr};    // 16x4096 path: W_L^(k1 t)
     // generic FFT twiddles per (L, dtype)
     std::map<std::pair<size_t, int>, void *> tw_cache;
     // small-path tables per (L, dtype): e^{2 pi i m / L}, m < L
@@ -182,6 +228,7 @@ struct caf_ctx {
     std::vector<hipStream_t> slot_pool;
     std::vector<bool> slot_busy;
     std::map<std::pair<hipStream_t, hipStream_t>, bool> overlap;  // streams_overlap() results
+    MeasureCtx *mz = nullptr;  // measurement build only (measure/dispatch.inc); always NULL in the product
 };
 
 struct caf_plan {
@@ -191,9 +238,6 @@ struct caf_plan {
     uint32_t fs = 0;
     size_t nfreq_total = 0, row_begin = 0, rows = 0;
     bool fused = false;
-    bool big = false;           // n == 32768 complex128: four-step tiled path
-    bool r32 = false;           // measurement build, CAF_R32=1: n = 32768 complex64 with 32 points per thread (kernels_r32.hpp)
-    void *r32_tw = nullptr, *r32_th = nullptr;
     bool small = false;         // n <= 512: lane-group rows (kernels_small.hpp)
     void *s_twL = nullptr;      //   ... its W_L table (borrowed from the ctx cache)
     bool chain = false;         // LDS-resident chain path (kernels_chain.hpp): R chains of 2^logm points
@@ -205,8 +249,6 @@ struct caf_plan {
     const void *stage_in_src = nullptr;  // streaming capture, fused path: the spectrum kernel also stages the needles in
     void *stage_in_dst = nullptr;
     size_t stage_in_bytes = 0;
-    bool bigq = false;          //   ... in its 16 x 4096 two-pass form (kernels_q65536.hpp)
-    DevBuf bwork, bhwork, bpart_val, bpart_idx;
     double *d_freqs = nullptr;  // this shard's slice
     double *d_ph = nullptr;
     // fused
@@ -216,15 +258,45 @@ struct caf_plan {
     // generic
     void *d_tw = nullptr;  // borrowed from ctx cache
     DevBuf wx, wy, hx, hy;
-    unsigned long long *dbg = nullptr;  // measurement build: diagnostic stamps buffer (caf_debug_set_stamps)
-    size_t dbg_len = 0;                 //   ... its length in u64
-    int variant = 0;                    // row kernel of n = 4096 plans: 0 sequential chains, 3 two chains in flight; 1, 2: measurement build only
     int live_streams = 0;               // caf_stream objects whose graphs hold this plan's buffers
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
+    MeasurePlan *mz = nullptr;  // measurement build only (measure/dispatch.inc); always NULL in the product
 };
+
+// forward declarations the measurement hooks use
+template <typename T>
+static int build_fused_tables(caf_ctx *c, int dt);
+static int timing_mark(caf_plan *p);
+
+// ------------------------------------------------- measurement-build hooks --
+// -DCAF_MEASURE (libcaf_hip_measure.so, used by tools/ and the variant tests only) compiles the rejected kernel
+// variants, the ablation instantiations (WRONG results, timing only) and the CAF_* environment switches that select
+// them: all of that lives in measure/dispatch.inc, behind the hooks below.  The product library has the no-op hooks,
+// contains none of those kernels and reads no environment variable.  This is the only conditional in this file.
+#ifdef CAF_MEASURE
+#include "measure/dispatch.inc"
+#else
+#define CHAIN_CASES_MEASURE_F32(STMT)
+static int measure_ctx_init(caf_ctx *) { return CAF_OK; }
+static void measure_ctx_free(caf_ctx *) {}
+static size_t measure_chain_mmax(int, size_t m_max) { return m_max; }
+static int measure_plan_select(caf_plan *) { return CAF_OK; }
+static void measure_plan_free(caf_plan *) {}
+static const char *measure_plan_path(const caf_plan *) { return nullptr; }
+static const char *measure_kernel_name(const caf_plan *) { return nullptr; }
+static bool measure_keeps_own_kernels(const caf_plan *) { return false; }
+static bool measure_own_stage_in(const caf_plan *) { return false; }
+template <typename T> static bool measure_plan_tables(caf_plan *, int *) { return false; }
+template <typename T> static void measure_fused_args(const caf_plan *, FusedArgs<T> &) {}
+template <typename T> static bool measure_fused_prepare(caf_plan *, FusedArgs<T> &, size_t) { return false; }
+static void measure_fused_tuning(bool *, size_t *) {}
+template <typename T> static bool measure_fused_rows(caf_plan *, FusedArgs<T> &, unsigned, size_t, int *) { return false; }
+template <typename T> static bool measure_chain_rows(caf_plan *, ChainArgs<T> &, const cpx<T> *, unsigned, int, int *) { return false; }
+static bool measure_surface_dev(caf_plan *, const void *, const void *, size_t, void *, uint64_t *, void *, int *) { return false; }
+#endif
 
 // ------------------------------------------------------------ small helpers --
 extern "C" int caf_abi_version(void) { return CAF_ABI_VERSION; }
@@ -243,8 +315,8 @@ template <typename T>
 static int build_fused_tables(caf_ctx *c, int dt)
 {
     if (c->tw4096[dt]) return CAF_OK;
-    HIPCHK(hipMalloc(&c->tw4096[dt], 4096 * sizeof(cpx<T>)));
-    HIPCHK(hipMalloc(&c->th[dt], 512 * sizeof(cpx<T>)));
+    HIPCHK(dev_alloc(&c->tw4096[dt], 4096 * sizeof(cpx<T>)));
+    HIPCHK(dev_alloc(&c->th[dt], 512 * sizeof(cpx<T>)));
     k_fused_tables<T><<<16, 256, 0, c->stream>>>((cpx<T> *)c->tw4096[dt], (cpx<T> *)c->th[dt]);
     KCHK();
     return CAF_OK;
@@ -258,7 +330,7 @@ static int get_generic_tw(caf_ctx *c, size_t L, int dt, void **out)
     if (it != c->tw_cache.end()) { *out = it->second; return CAF_OK; }
     const size_t half = L / 2 ? L / 2 : 1;
     void *p = nullptr;
-    HIPCHK(hipMalloc(&p, half * sizeof(cpx<T>)));
+    HIPCHK(dev_alloc(&p, half * sizeof(cpx<T>)));
     k_twiddle<T><<<(unsigned)((half + 255) / 256), 256, 0, c->stream>>>((cpx<T> *)p, half, L);
     KCHK();
     c->tw_cache[key] = p;
@@ -314,13 +386,18 @@ extern "C" int caf_ctx_create(int device_id, caf_ctx **out)
     HIPCHK(hipSetDevice(device_id));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    // the library holds gfx950 code objects only ("gfx950:sramecc+:xnack-" is what the runtime reports for an MI355X)
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CAF_ERR_NO_DEVICE, "device %d is %s, not gfx950 (MI355X): this library carries no code for it and has no CPU fallback",
+                    device_id, prop.gcnArchName);
     caf_ctx *c = new (std::nothrow) caf_ctx;
     if (!c) return fail(CAF_ERR_NOMEM, "out of host memory");
     c->device = device_id;
     c->cu_count = prop.multiProcessorCount;
     c->name = prop.gcnArchName;
+    if (int mrc = measure_ctx_init(c)) { delete c; return mrc; }
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete c; return fail(CAF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { measure_ctx_free(c); delete c; return fail(CAF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
     *out = c;
     return CAF_OK;
@@ -343,23 +420,19 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
     while (!c->host_slots.empty()) { host_slot_free(c->host_slots.back()); c->host_slots.pop_back(); }
     while (!c->plans.empty()) caf_plan_destroy(c->plans.back());  // user plans too: their tables live in this context
     for (int d = 0; d < 2; ++d) {
-        if (c->tw4096[d]) (void)hipFree(c->tw4096[d]);
-        if (c->th[d]) (void)hipFree(c->th[d]);
+        if (c->tw4096[d]) (void)dev_free(c->tw4096[d]);
+        if (c->th[d]) (void)dev_free(c->th[d]);
     }
-    for (int d = 0; d < 2; ++d) {
-        if (c->bigw256[d]) (void)hipFree(c->bigw256[d]);
-        if (c->bigwL[d]) (void)hipFree(c->bigwL[d]);
-        if (c->qoutw[d]) (void)hipFree(c->qoutw[d]);
-    }
+    measure_ctx_free(c);
     for (auto st_ : c->slot_pool)
         if (st_ != c->own_stream) (void)hipStreamDestroy(st_);
-    for (auto &kv : c->tw_cache) (void)hipFree(kv.second);
-    for (auto &kv : c->small_tabs) (void)hipFree(kv.second);
-    for (auto &kv : c->chain_tabs) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.second); }
+    for (auto &kv : c->tw_cache) (void)dev_free(kv.second);
+    for (auto &kv : c->small_tabs) (void)dev_free(kv.second);
+    for (auto &kv : c->chain_tabs) { (void)dev_free(kv.second.first); (void)dev_free(kv.second.second); }
     c->io_surface.release(); c->io_a.release(); c->io_b.release();
     c->pin_a.release(); c->pin_b.release();
     for (auto &kv : c->host_ranges) {
-        if (kv.second.owned) (void)hipHostFree(kv.first);
+        if (kv.second.owned) (void)pin_free(kv.first);
         else (void)hipHostUnregister(kv.first);
     }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -463,7 +536,7 @@ static int get_full_tw(caf_ctx *c, size_t n, int dt, void **out)
     auto it = c->small_tabs.find(key);
     if (it == c->small_tabs.end()) {
         void *tw = nullptr;
-        HIPCHK(hipMalloc(&tw, n * sizeof(cpx<T>)));
+        HIPCHK(dev_alloc(&tw, n * sizeof(cpx<T>)));
         k_twiddle<T><<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>((cpx<T> *)tw, n, n);
         KCHK();
         it = c->small_tabs.emplace(key, tw).first;
@@ -571,9 +644,7 @@ static bool chain_config(size_t n, int dtype, int *logm, int *R)
 {
     if (n < 1024 || n == (size_t)F_N || !is_pow2(n)) return false;
     size_t m_max = dtype == CAF_C64 ? 16384 : 8192;
-#ifdef CAF_MEASURE
-    if (dtype == CAF_C64 && measure_env("CAF_CHAIN_MMAX", 0)) m_max = (size_t)measure_env("CAF_CHAIN_MMAX", 0);  // 8192: shorter chains, more of them
-#endif
+    m_max = measure_chain_mmax(dtype, m_max);
     size_t M;
     if (n <= m_max) { M = n; *R = 2; }
     else if (n / 2 <= m_max) { M = n / 2; *R = 4; }
@@ -595,11 +666,6 @@ static bool chain_config(size_t n, int dtype, int *logm, int *R)
         (void)NB_;                                                                               \
         STMT;                                                                                    \
     } else
-#ifdef CAF_MEASURE
-#define CHAIN_CASES_MEASURE_F32(STMT) CHAIN_CASE(13, 4, STMT) CHAIN_CASE(13, 8, STMT)
-#else
-#define CHAIN_CASES_MEASURE_F32(STMT)
-#endif
 #define CHAIN_DISPATCH(T, logm, R, STMT)                                                               \
     do {                                                                                               \
         const int logm_ = (logm), R_rt = (R);                                                          \
@@ -623,8 +689,8 @@ static int build_chain_tables(caf_plan *p)
     auto it = c->chain_tabs.find(key);
     if (it == c->chain_tabs.end()) {
         void *twM = nullptr, *th = nullptr;
-        HIPCHK(hipMalloc(&twM, (size_t)M * sizeof(cpx<T>)));
-        HIPCHK(hipMalloc(&th, (size_t)(R - 1) * W * sizeof(cpx<T>)));
+        HIPCHK(dev_alloc(&twM, (size_t)M * sizeof(cpx<T>)));
+        HIPCHK(dev_alloc(&th, (size_t)(R - 1) * W * sizeof(cpx<T>)));
         k_chain_tables<T><<<(unsigned)((M + 255) / 256), 256, 0, c->stream>>>((cpx<T> *)twM, (cpx<T> *)th, M, R);
         KCHK();
         it = c->chain_tabs.emplace(key, std::make_pair(twM, th)).first;
@@ -633,7 +699,7 @@ static int build_chain_tables(caf_plan *p)
     p->c_th = it->second.second;
     const size_t nr = p->rows + 1;  // +1: the f = 0 row for the haystack transform
     const size_t PH = (size_t)chain_ph_v(R);
-    HIPCHK(hipMalloc(&p->d_phasor, nr * PH * sizeof(cpx<T>)));
+    HIPCHK(dev_alloc(&p->d_phasor, nr * PH * sizeof(cpx<T>)));
     k_chain_phasors<T><<<(unsigned)((nr * PH + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows, M, R,
                                                                                  (cpx<T> *)p->d_phasor);
     KCHK();
@@ -647,35 +713,7 @@ static int plan_build_tables(caf_plan *p)
     caf_ctx *c = p->ctx;
     const int dt = p->dtype;
     int rc;
-#ifdef CAF_MEASURE
-    if (p->big && p->bigq) {
-        if ((rc = build_fused_tables<T>(c, dt))) return rc;  // W_4096 for the 4096-point chains
-        if (!c->qoutw[dt]) {
-            HIPCHK(hipMalloc(&c->qoutw[dt], 4096 * sizeof(cpx<T>)));
-            k_q_tables<T><<<16, 256, 0, c->stream>>>((cpx<T> *)c->qoutw[dt]);
-            KCHK();
-        }
-        const size_t nr = p->rows + 1;  // +1: the w = 1 row of the haystack transform
-        HIPCHK(hipMalloc(&p->d_phasor, nr * 1024 * sizeof(cpx<T>)));
-        k_q_phasors<T><<<(unsigned)((nr * 1024 + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows,
-                                                                                 (cpx<T> *)p->d_phasor);
-        KCHK();
-        return CAF_OK;
-    }
-#endif
-#ifdef CAF_MEASURE
-    if (p->r32) {
-        HIPCHK(hipMalloc(&p->r32_tw, (size_t)W_M * sizeof(cpx<T>)));
-        HIPCHK(hipMalloc(&p->r32_th, (size_t)3 * W_T * sizeof(cpx<T>)));
-        k_r32_tables<T><<<W_M / 256, 256, 0, c->stream>>>((cpx<T> *)p->r32_tw, (cpx<T> *)p->r32_th);
-        KCHK();
-        const size_t nr = p->rows + 1;
-        HIPCHK(hipMalloc(&p->d_phasor, nr * W_PH * sizeof(cpx<T>)));
-        k_r32_phasors<T><<<(unsigned)((nr * W_PH + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows, (cpx<T> *)p->d_phasor);
-        KCHK();
-        return CAF_OK;
-    }
-#endif
+    if (measure_plan_tables<T>(p, &rc)) return rc;  // (measurement build: tables of a selected variant)
     if (p->chain) return build_chain_tables<T>(p);
     if (p->small) {
         if ((rc = get_full_tw<T>(c, p->L, dt, &p->s_twL))) return rc;
@@ -683,42 +721,20 @@ static int plan_build_tables(caf_plan *p)
         // runs the two sincos itself (same function, same arguments: same bits).
         const size_t tpr = p->L / 16, entries = p->rows * (tpr + 1);
         if (p->L >= 16 && p->rows && entries * sizeof(cpx<double>) <= ((size_t)256 << 20)) {
-            HIPCHK(hipMalloc(&p->d_phasor, entries * sizeof(cpx<double>)));
+            HIPCHK(dev_alloc(&p->d_phasor, entries * sizeof(cpx<double>)));
             k_small_phasors<<<(unsigned)((entries + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows, (int)tpr,
                                                                                     (cpx<double> *)p->d_phasor);
             KCHK();
         }
         return CAF_OK;
     }
-#ifdef CAF_MEASURE
-    if (p->big) {
-        if (!c->bigw256[dt]) {
-            HIPCHK(hipMalloc(&c->bigw256[dt], 256 * sizeof(cpx<T>)));
-            HIPCHK(hipMalloc(&c->bigwL[dt], 256 * sizeof(cpx<T>)));
-            k_big_tables<T><<<1, 256, 0, c->stream>>>((cpx<T> *)c->bigw256[dt], (cpx<T> *)c->bigwL[dt]);
-            KCHK();
-        }
-        const size_t nr = p->rows + 1;
-        HIPCHK(hipMalloc(&p->d_phasor, nr * 384 * sizeof(cpx<T>)));
-        k_big_phasors<T><<<(unsigned)((nr * 384 + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows,
-                                                                                   (cpx<T> *)p->d_phasor);
-        KCHK();
-        return CAF_OK;
-    }
-#endif
     if (p->fused) {
         if ((rc = build_fused_tables<T>(c, dt))) return rc;
         const size_t nr = p->rows + 1;  // +1: the f = 0 row for the haystack transform
-        HIPCHK(hipMalloc(&p->d_phasor, nr * 64 * sizeof(cpx<T>)));
+        HIPCHK(dev_alloc(&p->d_phasor, nr * 64 * sizeof(cpx<T>)));
         const size_t threads = nr * 64;
-#ifdef CAF_MEASURE
-        if (p->variant == 2)
-            k_r8_phasors<T><<<(unsigned)((threads + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows,
-                                                                                       (cpx<T> *)p->d_phasor);
-        else
-#endif
-            k_fused_phasors<T><<<(unsigned)((threads + 255) / 256), 256, 0, c->stream>>>(
-                p->d_ph, (int)p->rows, (cpx<T> *)p->d_phasor);
+        k_fused_phasors<T><<<(unsigned)((threads + 255) / 256), 256, 0, c->stream>>>(p->d_ph, (int)p->rows,
+                                                                                    (cpx<T> *)p->d_phasor);
         KCHK();
     } else {
         if ((rc = get_generic_tw<T>(c, p->L, dt, &p->d_tw))) return rc;
@@ -751,29 +767,15 @@ extern "C" int caf_plan_create(caf_ctx *c, size_t n, const double *freqs_hz, siz
     p->row_begin = row_begin;
     p->rows = row_end - row_begin;
     p->fused = (n == (size_t)F_N);
-    p->small = n <= 512 && measure_env("CAF_SMALL", 1) != 0;  // (CAF_SMALL=0, measurement build: the radix-2 passes over HBM)
-    // (CAF_CHAIN=0, measurement build: keep the older tiled65536 / generic paths reachable for comparison)
-    p->chain = measure_env("CAF_CHAIN", 1) != 0 && chain_config(n, dtype, &p->clogm, &p->cR);
-    p->r32 = p->chain && n == 32768 && dtype == CAF_C64 && measure_env("CAF_R32", 0) >= 1;
-#ifdef CAF_MEASURE
-    p->big = !p->chain && (n == (size_t)B_N);  // only reachable with CAF_CHAIN=0
-#endif
-    p->variant = dtype == CAF_C64 ? 3 : 0;  // f32: two chains in flight; f64: sequential chains (kernels_duo4096.hpp)
-    // measurement build only: CAF_BIG_PATH=1 = the 16 x 4096 two-pass form (parity-green, 2.63 vs 2.19 ms per
-    // 4096-row surface); CAF_ROW_KERNEL = 0..3 picks the n = 4096 row kernel.  No-ops in the product library.
-    p->bigq = p->big && measure_env("CAF_BIG_PATH", 0) == 1;
-    p->variant = (int)measure_env("CAF_ROW_KERNEL", p->variant);
-    if (p->variant < 0 || p->variant > 3) {
-        const int bad = p->variant;
-        delete p;
-        return fail(CAF_ERR_BAD_ARG, "CAF_ROW_KERNEL=%d: no such row kernel", bad);
-    }
+    p->small = n <= 512;                                         // lane-group rows (kernels_small.hpp)
+    p->chain = chain_config(n, dtype, &p->clogm, &p->cR);        // LDS-resident chains (kernels_chain.hpp)
     int rc = CAF_OK;
     auto bail = [&](int code) { caf_plan_destroy(p); return code; };
+    if ((rc = measure_plan_select(p))) return bail(rc);  // (measurement build: the environment may pick a variant)
     if (p->rows) {
         hipError_t e;
-        if ((e = hipMalloc((void **)&p->d_freqs, p->rows * sizeof(double))) != hipSuccess ||
-            (e = hipMalloc((void **)&p->d_ph, p->rows * sizeof(double))) != hipSuccess)
+        if ((e = dev_alloc((void **)&p->d_freqs, p->rows * sizeof(double))) != hipSuccess ||
+            (e = dev_alloc((void **)&p->d_ph, p->rows * sizeof(double))) != hipSuccess)
             return bail(fail(CAF_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e)));
         // pageable H2D on a stream is synchronous w.r.t. the host buffer: safe to borrow
         if ((e = hipMemcpyAsync(p->d_freqs, freqs_hz + row_begin, p->rows * sizeof(double),
@@ -804,14 +806,12 @@ extern "C" int caf_plan_destroy(caf_plan *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     for (auto it = p->ctx->plans.begin(); it != p->ctx->plans.end(); ++it)
         if (*it == p) { p->ctx->plans.erase(it); break; }
-    if (p->d_freqs) (void)hipFree(p->d_freqs);
-    if (p->d_ph) (void)hipFree(p->d_ph);
-    if (p->d_phasor) (void)hipFree(p->d_phasor);
-    if (p->r32_tw) (void)hipFree(p->r32_tw);
-    if (p->r32_th) (void)hipFree(p->r32_th);
+    if (p->d_freqs) (void)dev_free(p->d_freqs);
+    if (p->d_ph) (void)dev_free(p->d_ph);
+    if (p->d_phasor) (void)dev_free(p->d_phasor);
     p->spec.release(); p->wx.release(); p->wy.release(); p->hx.release(); p->hy.release();
-    p->bwork.release(); p->bhwork.release(); p->bpart_val.release(); p->bpart_idx.release();
     p->slab.release();
+    measure_plan_free(p);
     for (auto ev : p->ev) (void)hipEventDestroy(ev);
     delete p;
     return CAF_OK;
@@ -820,14 +820,16 @@ extern "C" int caf_plan_destroy(caf_plan *p)
 
 extern "C" const char *caf_plan_path(const caf_plan *p)
 {
-    return !p ? "" : p->fused ? "fused4096" : p->chain ? "chain" : p->small ? "small" : p->big ? "tiled65536" : "generic";
+    if (!p) return "";
+    if (const char *m = measure_plan_path(p)) return m;
+    return p->fused ? "fused4096" : p->chain ? "chain" : p->small ? "small" : "generic";
 }
 extern "C" size_t caf_plan_rows(const caf_plan *p) { return p ? p->rows : 0; }
 extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
 {
     if (!p) return "";
     const bool f64 = p->dtype == CAF_C128;
-    if (p->r32) return "caf::k_r32_rows<float>";
+    if (const char *m = measure_kernel_name(p)) return m;
     if (p->chain) {
         static thread_local char name[64];
         snprintf(name, sizeof name, "caf::k_chain_rows<%s, %d, %d, %d, 0>", f64 ? "double" : "float", p->clogm, p->cR,
@@ -842,13 +844,8 @@ extern "C" const char *caf_plan_kernel_name(const caf_plan *p)
         else snprintf(name, sizeof name, "caf::k_small<%s, %d, false>", f64 ? "double" : "float", lg);
         return name;
     }
-    if (p->big && p->bigq) return f64 ? "caf::k_q_rows<double, 1>" : "caf::k_q_rows<float, 2>";  // measurement build
-    if (p->big) return f64 ? "caf::k_big_rows<double>" : "caf::k_big_rows<float>";  // measurement build
     if (!p->fused) return f64 ? "caf::k_fft_pass<double, 16>" : "caf::k_fft_pass<float, 16>";
-    if (p->variant == 0) return f64 ? "caf::k_seq_rows<double, 15, caf::SeqIo<double> >" : "caf::k_seq_rows<float, 15, caf::SeqIo<float> >";
-    if (p->variant == 2) return f64 ? "caf::k_r8_rows<double, 0>" : "caf::k_r8_rows<float, 0>";
-    if (p->variant == 3) return f64 ? "caf::k_duo_rows<double, caf::DuoIo<double> >" : "caf::k_duo_rows<float, caf::DuoIo<float> >";
-    return f64 ? "caf::k_fused_rows<double, false>" : "caf::k_fused_rows<float, false>";
+    return f64 ? "caf::k_seq_rows<double, 15, caf::SeqIo<double> >" : "caf::k_duo_rows<float, caf::DuoIo<float> >";
 }
 
 static int timing_mark(caf_plan *p)
@@ -893,29 +890,6 @@ extern "C" int caf_plan_timing_end(caf_plan *p, double *ms_total, uint64_t *laun
     CAF_GUARD_END
 }
 
-#ifdef CAF_MEASURE
-// Measurement build only (not in include/caf_hip.h): route the next caf_surface_dev calls of an
-// n = 4096 plan through the stamped DIAG instantiation of the lane-half kernel (CAF_ROW_KERNEL=1,
-// k_fused_rows<T,true>: 32*8*F_NSTAMP words).  d_buf = `len_u64` device u64 words or NULL to stop.  The other
-// variants have no DIAG build (the stamped form of k_seq_rows went with round 3's clean-up of that kernel).
-extern "C" int caf_debug_set_stamps(caf_plan *p, void *d_buf, size_t len_u64)
-{
-    CAF_GUARD_BEGIN
-    if (!p) return fail(CAF_ERR_BAD_ARG, "plan is NULL");
-    if (d_buf) {
-        if (!p->fused || p->variant != 1)
-            return fail(CAF_ERR_BAD_ARG, "caf_debug_set_stamps: row kernel variant %d has no stamped build", p->variant);
-        const size_t need = (size_t)32 * 8 * F_NSTAMP;
-        if (len_u64 < need)
-            return fail(CAF_ERR_BAD_ARG, "caf_debug_set_stamps: buffer of %zu u64 words, %zu needed", len_u64, need);
-    }
-    p->dbg = (unsigned long long *)d_buf;
-    p->dbg_len = d_buf ? len_u64 : 0;
-    return CAF_OK;
-    CAF_GUARD_END
-}
-#endif
-
 // ------------------------------------------------------------ surface (dev) --
 template <typename T>
 static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch,
@@ -933,7 +907,8 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     a.work = (unsigned *)((unsigned char *)a.spec + spec_bytes);
     a.rows = (int)p->rows;
     a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr;
-    a.dbg = p->dbg;
+    a.dbg = nullptr;
+    measure_fused_args(p, a);
     a.stage_src = (const uint4 *)p->stage_in_src;
     a.stage_dst = (uint4 *)p->stage_in_dst;
     a.stage_n16 = (unsigned)(p->stage_in_bytes / 16);
@@ -941,13 +916,7 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     // xcor_rustfft.rs:58-59)
     a.sig = (const cpx<T> *)d_hay;
     a.total = (int)batch;
-#ifdef CAF_MEASURE
-    if (p->variant == 2) {
-        const unsigned prep_grid = (unsigned)(batch < (size_t)c->cu_count ? batch : (size_t)c->cu_count);
-        k_r8_prepare<T><<<prep_grid, R_THREADS, 0, c->stream>>>(a);
-    } else
-#endif
-    {  // one workgroup per (surface, chain): halves the latency of a single-surface call
+    if (!measure_fused_prepare<T>(p, a, batch)) {  // one workgroup per (surface, chain): halves the latency of a single-surface call
         const size_t want = 2 * batch, cap2 = 2 * (size_t)c->cu_count;
         a.fft_blocks = (unsigned)(want < cap2 ? want : cap2);
         const size_t copy_want = ((size_t)a.stage_n16 + S_THREADS - 1) / S_THREADS;  // streaming slots only
@@ -959,57 +928,27 @@ static int surface_dev_fused(caf_plan *p, const void *d_needle, const void *d_ha
     if (total == 0) return CAF_OK;
     // Dynamic row tickets pay off from ~6 rows per resident workgroup; below that the static
     // stride (no atomic, no LDS round trip per row) is 2-7 % faster (measured at batch 1-16).
-    // (CAF_STATIC_ROWS, measurement build: static striding for every launch size.)
-    if (measure_env("CAF_STATIC_ROWS", 0) || total <= 4 * (size_t)c->cu_count * 2) a.work = nullptr;
+    bool static_rows = total <= 4 * (size_t)c->cu_count * 2;
+    // resident workgroups per CU: LDS- and VGPR-limited (2 in f64, 3 in f32)
+    size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
+    if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();
+    measure_fused_tuning(&static_rows, &per_cu);
+    if (static_rows) a.work = nullptr;
     a.sig = (const cpx<T> *)d_needle;
     a.total = (int)total;
     a.surface = (T *)d_surface;
     a.row_idx = d_ridx;
     a.row_val = (T *)d_rval;
     if ((rc = timing_mark(p))) return rc;
-    // resident workgroups per CU: LDS- and VGPR-limited (2 in f64, 3 in f32)
-    size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
-    if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();
-    if (measure_env("CAF_WG_PER_CU", 0) > 0) per_cu = (size_t)measure_env("CAF_WG_PER_CU", 0);
     const size_t cap = (size_t)c->cu_count * per_cu;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
-#ifdef CAF_MEASURE
-    const int store_mode = (int)measure_env("CAF_STORE_MODE", 0);
-    if (p->variant == 2) {
-        const size_t cap8 = (size_t)c->cu_count * 2;
-        const unsigned g8 = (unsigned)(total < cap8 ? total : cap8);
-        if (store_mode == 3)
-            k_r8_rows<T, 3><<<g8, R_THREADS, 0, c->stream>>>(a);
-        else
-            k_r8_rows<T, 0><<<g8, R_THREADS, 0, c->stream>>>(a);
-    } else if (p->variant == 1) {
-        const size_t capf = (size_t)c->cu_count * (fused_lds_bytes<T>() * 2 <= 160 * 1024 ? 2 : 1);
-        const unsigned gf = (unsigned)(total < capf ? total : capf);
-        if (p->dbg)
-            k_fused_rows<T, true><<<gf, F_THREADS, 0, c->stream>>>(a);
-        else
-            k_fused_rows<T, false><<<gf, F_THREADS, 0, c->stream>>>(a);
-    } else if (p->variant == 3 && store_mode == 3) {
-        k_duo_rows<T, DuoIoNoStore<T>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
-    } else if (p->variant == 3 && store_mode == 33) {  // VALU only: the product body over the null memory policy
-        k_duo_rows<T, DuoIoNull<T>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);
-    } else if (p->variant == 0 && store_mode != 0) {
-        switch (store_mode) {  // measurement policies over the product kernel body (WRONG results, timing only), and PF = 0
-        case 3: k_seq_rows<T, 15, SeqIoCut<T, 4>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;   // no surface stores
-        case 31: k_seq_rows<T, 15, SeqIoCut<T, 1>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS traffic / barriers
-        case 32: k_seq_rows<T, 15, SeqIoCut<T, 2>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no global loads
-        case 33: k_seq_rows<T, 15, SeqIoCut<T, 7>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // VALU only
-        case 34: k_seq_rows<T, 15, SeqIoCut<T, 5>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no LDS, no stores
-        case 35: k_seq_rows<T, 15, SeqIoCut<T, 6>><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;  // no loads, no stores
-        case 20: k_seq_rows<T, 0><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor); break;                    // no software pipelining (correct results)
-        default: return fail(CAF_ERR_BAD_ARG, "CAF_STORE_MODE=%d: no such measurement mode", store_mode);
-        }
-    } else
-#endif
-    if (p->variant == 3)
-        k_duo_rows<T><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex64 product kernel
-    else
-        k_seq_rows<T><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex128 product kernel
+    if (measure_fused_rows<T>(p, a, grid, total, &rc)) {  // (measurement build: a selected variant / ablation launched instead)
+        if (rc) return rc;
+    } else if constexpr (sizeof(T) == 4) {
+        k_duo_rows<T><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex64 product kernel: two chains in flight
+    } else {
+        k_seq_rows<T><<<grid, S_THREADS, 0, c->stream>>>(a, a.phasor);  // complex128 product kernel: sequential chains
+    }
     KCHK();
     if ((rc = timing_mark(p))) return rc;
     return CAF_OK;
@@ -1073,123 +1012,6 @@ static int surface_single_launch(caf_plan *p, hipStream_t on, const void *needle
     return CAF_OK;
 }
 
-#ifdef CAF_MEASURE
-// n = 32768 as 16 x 4096: two passes (kernels_q65536.hpp)
-template <typename T>
-static int surface_dev_q(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
-                         uint64_t *d_ridx, void *d_rval)
-{
-    caf_ctx *c = p->ctx;
-    const size_t rows = p->rows, total = batch * rows;
-    constexpr int RES = q_res<T>();
-    int rc;
-    if (!p->spec_override && (rc = p->spec.ensure(batch * B_L * sizeof(cpx<T>)))) return rc;
-    QArgs<T> a;
-    a.tw4096 = (const cpx<T> *)c->tw4096[p->dtype];
-    a.outw = (const cpx<T> *)c->qoutw[p->dtype];
-    a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
-    a.rows = (int)rows;
-    a.work = nullptr; a.surface = nullptr; a.part_val = nullptr; a.part_idx = nullptr;
-    size_t per_cu = 160 * 1024 / seq_lds_bytes<T>();
-    if (per_cu > (size_t)seq_waves_per_simd<T>()) per_cu = seq_waves_per_simd<T>();
-    const size_t cap = (size_t)c->cu_count * per_cu;
-    const cpx<T> *phasor = (const cpx<T> *)p->d_phasor;
-    // haystack spectrum once per surface: the row kernel's front half with w = 1
-    a.prepare = 1;
-    a.sig = (const cpx<T> *)d_hay;
-    for (size_t w0 = 0; w0 < batch; w0 += 32768) {
-        const size_t nw = batch - w0 < 32768 ? batch - w0 : 32768;
-        a.wr0 = (unsigned)w0;
-        a.nw = (unsigned)nw;
-        const size_t tasks = nw * (16 / RES);
-        k_q_rows<T, RES><<<(unsigned)(tasks < cap ? tasks : cap), S_THREADS, 0, c->stream>>>(a, phasor);
-    }
-    KCHK();
-    if (total == 0) return CAF_OK;
-    // chunks of rows share one Infinity-Cache-resident work buffer (see surface_dev_big)
-    const size_t chunk_env = (size_t)measure_env("CAF_BIG_CHUNK", 0);  // measurement build only
-    size_t chunk = chunk_env ? chunk_env : (128u << 20) / (B_L * sizeof(cpx<T>));
-    if (chunk < 1) chunk = 1;
-    if (chunk > 32768) chunk = 32768;
-    if ((rc = p->bwork.ensure((total < chunk ? total : chunk) * B_L * sizeof(cpx<T>)))) return rc;
-    if ((rc = p->bpart_val.ensure(total * 8 * sizeof(T)))) return rc;
-    if ((rc = p->bpart_idx.ensure(total * 8 * sizeof(uint32_t)))) return rc;
-    a.prepare = 0;
-    a.sig = (const cpx<T> *)d_needle;
-    a.work = (cpx<T> *)p->bwork.p;
-    a.surface = (T *)d_surface;
-    a.part_val = (T *)p->bpart_val.p;
-    a.part_idx = (uint32_t *)p->bpart_idx.p;
-    if ((rc = timing_mark(p))) return rc;
-    const size_t cap_cols = (size_t)c->cu_count * 4;
-    for (size_t w0 = 0; w0 < total; w0 += chunk) {
-        const size_t nw = total - w0 < chunk ? total - w0 : chunk;
-        a.wr0 = (unsigned)w0;
-        a.nw = (unsigned)nw;
-        const size_t tasks = nw * (16 / RES), ctasks = nw * 8;
-        k_q_rows<T, RES><<<(unsigned)(tasks < cap ? tasks : cap), S_THREADS, 0, c->stream>>>(a, phasor);
-        k_q_cols<T><<<(unsigned)(ctasks < cap_cols ? ctasks : cap_cols), 256, 0, c->stream>>>(a);
-    }
-    KCHK();
-    k_q_rowpeak<T><<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(
-        (const T *)p->bpart_val.p, (const uint32_t *)p->bpart_idx.p, total, d_ridx, (T *)d_rval);
-    KCHK();
-    if ((rc = timing_mark(p))) return rc;
-    return CAF_OK;
-}
-#endif  // CAF_MEASURE
-
-#ifdef CAF_MEASURE
-// n = 32768 complex64 with 32 points per thread (kernels_r32.hpp)
-static int surface_dev_r32(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
-                           uint64_t *d_ridx, void *d_rval)
-{
-    using T = float;
-    caf_ctx *c = p->ctx;
-    const size_t total = batch * p->rows;
-    int rc;
-    if (!p->spec_override && (rc = p->spec.ensure(batch * (size_t)W_L * sizeof(cpx<T>)))) return rc;
-    R32Args<T> a;
-    a.twM = (const cpx<T> *)p->r32_tw;
-    a.th = (const cpx<T> *)p->r32_th;
-    a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
-    a.rows = (int)p->rows;
-    a.surface = nullptr; a.row_idx = nullptr; a.row_val = nullptr; a.slab = nullptr;
-    const cpx<T> *phasor = (const cpx<T> *)p->d_phasor;
-    const size_t cap = (size_t)c->cu_count;
-    a.sig = (const cpx<T> *)d_hay;
-    a.total = (int)batch;
-    {
-        const size_t want = (size_t)W_R * batch;
-        k_r32_prepare<T><<<(unsigned)(want < cap ? want : cap), W_T, 0, c->stream>>>(a, phasor);
-    }
-    KCHK();
-    if (total == 0) return CAF_OK;
-    const unsigned grid = (unsigned)(total < cap ? total : cap);
-    if (!p->slab_override && (rc = p->slab.ensure(cap * 64 * W_T * sizeof(cpx<T>)))) return rc;
-    a.slab = (cpx<T> *)(p->slab_override ? p->slab_override : p->slab.p);
-    a.sig = (const cpx<T> *)d_needle;
-    a.total = (int)total;
-    a.surface = (T *)d_surface;
-    a.row_idx = d_ridx;
-    a.row_val = (T *)d_rval;
-    if ((rc = timing_mark(p))) return rc;
-    switch ((int)measure_env("CAF_R32", 1)) {  // 1: the kernel; > 1: 1 + ablation mask (wrong results, timing only)
-    case 1: k_r32_rows<T, 0><<<grid, W_T, 0, c->stream>>>(a, phasor); break;
-    case 2: k_r32_rows<T, 1><<<grid, W_T, 0, c->stream>>>(a, phasor); break;    // no slab
-    case 3: k_r32_rows<T, 2><<<grid, W_T, 0, c->stream>>>(a, phasor); break;    // no surface stores
-    case 16: k_r32_rows<T, 15><<<grid, W_T, 0, c->stream>>>(a, phasor); break;  // no global memory
-    case 32: k_r32_rows<T, 31><<<grid, W_T, 0, c->stream>>>(a, phasor); break;  // ... and no workgroup barriers
-    case 33: k_r32_rows<T, 32><<<grid, W_T, 0, c->stream>>>(a, phasor); break;  // half the slab traffic (only b)
-    case 102: k_r32_rows<T, 0, 2><<<grid, W_T, 0, c->stream>>>(a, phasor); break;
-    case 104: k_r32_rows<T, 0, 4><<<grid, W_T, 0, c->stream>>>(a, phasor); break;
-    default: return fail(CAF_ERR_BAD_ARG, "CAF_R32=%ld: no such variant", measure_env("CAF_R32", 1));
-    }
-    KCHK();
-    return timing_mark(p);
-}
-#endif
-
 // LDS-resident chain path (kernels_chain.hpp)
 template <typename T>
 static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
@@ -1232,30 +1054,11 @@ static int surface_dev_chain(caf_plan *p, const void *d_needle, const void *d_ha
     a.row_idx = d_ridx;
     a.row_val = (T *)d_rval;
     if ((rc = timing_mark(p))) return rc;
-#ifdef CAF_MEASURE
-    // CAF_CHAIN_ABL (bit mask of measure/kernels_ablate.hpp ChainIoCut): ablations of the configs[3] kernel, WRONG results;
-    // 200: two butterflies per thread (correct results, measured and rejected)
-    if constexpr (sizeof(T) == 4) {
-        const int abl = (int)measure_env("CAF_CHAIN_ABL", 0);
-        if (abl && p->clogm == 14 && R == 4) {
-            switch (abl) {
-            case 1: k_chain_rows<T, 14, 4, 1, 1><<<grid, W, 0, c->stream>>>(a, phasor); break;
-            case 2: k_chain_rows<T, 14, 4, 1, 2><<<grid, W, 0, c->stream>>>(a, phasor); break;
-            case 4: k_chain_rows<T, 14, 4, 1, 4><<<grid, W, 0, c->stream>>>(a, phasor); break;
-            case 8: k_chain_rows<T, 14, 4, 1, 8><<<grid, W, 0, c->stream>>>(a, phasor); break;
-            case 16: k_chain_rows<T, 14, 4, 1, 16><<<grid, W, 0, c->stream>>>(a, phasor); break;
-            case 30: k_chain_rows<T, 14, 4, 1, 30><<<grid, W, 0, c->stream>>>(a, phasor); break;
-            case 31: k_chain_rows<T, 14, 4, 1, 31><<<grid, W, 0, c->stream>>>(a, phasor); break;
-            case 159: k_chain_rows<T, 14, 4, 1, 159><<<grid, W, 0, c->stream>>>(a, phasor); break;  // arithmetic only
-            case 128: k_chain_rows<T, 14, 4, 1, 128><<<grid, W, 0, c->stream>>>(a, phasor); break;  // no LDS chain traffic
-            case 200: k_chain_rows<T, 14, 4, 2, 0><<<grid, W / 2, 0, c->stream>>>(a, phasor); break;  // two butterflies per thread (correct results)
-            default: return fail(CAF_ERR_BAD_ARG, "CAF_CHAIN_ABL=%d: no such ablation", abl);
-            }
-            KCHK();
-            return timing_mark(p);
-        }
+    if (measure_chain_rows<T>(p, a, phasor, grid, W, &rc)) {  // (measurement build: ablations of the configs[3] kernel)
+        if (rc) return rc;
+        KCHK();
+        return timing_mark(p);
     }
-#endif
     CHAIN_DISPATCH(T, p->clogm, R, (k_chain_rows<T, LOGM_, R_, NB_><<<grid, W / NB_, 0, c->stream>>>(a, phasor)));
     KCHK();
     if ((rc = timing_mark(p))) return rc;
@@ -1325,77 +1128,6 @@ static int surface_dev_small(caf_plan *p, const void *d_needle, const void *d_ha
     }
 }
 
-#ifdef CAF_MEASURE
-// n = 32768: four-step tiled path (kernels_big65536.hpp)
-template <typename T>
-static int surface_dev_big(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch, void *d_surface,
-                           uint64_t *d_ridx, void *d_rval)
-{
-    caf_ctx *c = p->ctx;
-    const size_t rows = p->rows, total = batch * rows;
-    int rc;
-    if ((rc = p->bhwork.ensure((batch < 32768 ? batch : 32768) * B_L * sizeof(cpx<T>)))) return rc;
-    if (!p->spec_override && (rc = p->spec.ensure(batch * B_L * sizeof(cpx<T>)))) return rc;
-    BigArgs<T> a;
-    a.phasor = (const cpx<T> *)p->d_phasor;
-    a.w256 = (const cpx<T> *)c->bigw256[p->dtype];
-    a.wL = (const cpx<T> *)c->bigwL[p->dtype];
-    a.spec = (cpx<T> *)(p->spec_override ? p->spec_override : p->spec.p);
-    a.rows = (int)rows;
-    a.surface = nullptr; a.part_val = nullptr; a.part_idx = nullptr;
-    // persistent launches: 16 tiles x gy_cap rows of workgroups ~ one resident set; each loops over its rows
-    const size_t gy_env = (size_t)measure_env("CAF_BIG_GY", 0);  // measurement build only
-    const size_t gy_cap = gy_env ? gy_env : (size_t)c->cu_count * 3 / 16;  // 2.19-2.26 ms per 4096-row surface for 32...96
-    // haystack spectrum once per surface
-    a.prepare = 1;
-    a.sig = (const cpx<T> *)d_hay;
-    a.work = (cpx<T> *)p->bhwork.p;
-    for (size_t w0 = 0; w0 < batch; w0 += 32768) {
-        const size_t nw = batch - w0 < 32768 ? batch - w0 : 32768;
-        a.wr0 = (unsigned)w0;
-        a.nw = (unsigned)nw;
-        const unsigned gy = (unsigned)(nw < gy_cap ? nw : gy_cap);
-        k_big_cols_fwd<T><<<dim3(16, gy), B_THREADS, 0, c->stream>>>(a);
-        k_big_rows<T><<<dim3(16, gy), B_THREADS, 0, c->stream>>>(a);
-    }
-    KCHK();
-    if (total == 0) return CAF_OK;
-    // Rows are processed in chunks whose work rows (chunk x 64 Ki complex) fit the 256 MiB
-    // Infinity Cache, and every chunk reuses the SAME work buffer: the two intermediate passes
-    // hit on-die, and the intermediate data is overwritten in the cache instead of being
-    // written back to HBM once per row.
-    const size_t chunk_env = (size_t)measure_env("CAF_BIG_CHUNK", 0);  // measurement build only
-    size_t chunk = chunk_env ? chunk_env : (128u << 20) / (B_L * sizeof(cpx<T>));
-    if (chunk < 1) chunk = 1;
-    if (chunk > 32768) chunk = 32768;
-    if ((rc = p->bwork.ensure((total < chunk ? total : chunk) * B_L * sizeof(cpx<T>)))) return rc;
-    if ((rc = p->bpart_val.ensure(total * 16 * sizeof(T)))) return rc;
-    if ((rc = p->bpart_idx.ensure(total * 16 * sizeof(uint32_t)))) return rc;
-    a.prepare = 0;
-    a.sig = (const cpx<T> *)d_needle;
-    a.work = (cpx<T> *)p->bwork.p;
-    a.surface = (T *)d_surface;
-    a.part_val = (T *)p->bpart_val.p;
-    a.part_idx = (uint32_t *)p->bpart_idx.p;
-    if ((rc = timing_mark(p))) return rc;
-    for (size_t w0 = 0; w0 < total; w0 += chunk) {
-        const size_t nw = total - w0 < chunk ? total - w0 : chunk;
-        a.wr0 = (unsigned)w0;
-        a.nw = (unsigned)nw;
-        const unsigned gy = (unsigned)(nw < gy_cap ? nw : gy_cap);
-        k_big_cols_fwd<T><<<dim3(16, gy), B_THREADS, 0, c->stream>>>(a);
-        k_big_rows<T><<<dim3(16, gy), B_THREADS, 0, c->stream>>>(a);
-        k_big_cols_inv<T><<<dim3(16, gy), B_THREADS, 0, c->stream>>>(a);
-    }
-    KCHK();
-    k_big_rowpeak<T><<<(unsigned)((total + 255) / 256), 256, 0, c->stream>>>(
-        (const T *)p->bpart_val.p, (const uint32_t *)p->bpart_idx.p, total, d_ridx, (T *)d_rval);
-    KCHK();
-    if ((rc = timing_mark(p))) return rc;
-    return CAF_OK;
-}
-#endif  // CAF_MEASURE
-
 template <typename T>
 static int surface_dev_generic(caf_plan *p, const void *d_needle, const void *d_hay, size_t batch,
                                void *d_surface, uint64_t *d_ridx, void *d_rval)
@@ -1458,26 +1190,17 @@ extern "C" int caf_surface_dev(caf_plan *p, const void *d_needle, const void *d_
     caf_ctx *c = p->ctx;
     HIPCHK(hipSetDevice(c->device));
     int rc;
-    if (p->dtype == CAF_C128)
+    if (measure_surface_dev(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval, &rc)) {
+        // (measurement build: one of the older whole-surface paths ran instead)
+    } else if (p->dtype == CAF_C128)
         rc = p->fused ? surface_dev_fused<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->chain ? surface_dev_chain<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->small ? surface_dev_small<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
-#ifdef CAF_MEASURE
-             : p->big && p->bigq ? surface_dev_q<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
-             : p->big ? surface_dev_big<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
-#endif
                       : surface_dev_generic<double>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     else
         rc = p->fused ? surface_dev_fused<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
-#ifdef CAF_MEASURE
-             : p->r32 ? surface_dev_r32(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
-#endif
              : p->chain ? surface_dev_chain<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
              : p->small ? surface_dev_small<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
-#ifdef CAF_MEASURE
-             : p->big && p->bigq ? surface_dev_q<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
-             : p->big ? surface_dev_big<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval)
-#endif
                       : surface_dev_generic<float>(p, d_needle, d_hay, batch, d_surface, d_ridx, d_rval);
     if (rc) return rc;
     // find_peak (mod.rs:31-42)
@@ -1507,9 +1230,9 @@ static void host_slot_free(HostSlot *s)
 {
     if (!s) return;
     if (s->plan) caf_plan_destroy(s->plan);
-    if (s->h_base) (void)hipHostFree(s->h_base);
+    if (s->h_base) (void)pin_free(s->h_base);
     for (void *p : {s->d_needle, s->d_ridx, s->d_rval, s->d_peak, s->d_spec, s->d_slab, (void *)s->d_sync})
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
     delete s;
 }
 
@@ -1542,9 +1265,7 @@ static int get_host_slot(caf_ctx *c, size_t n, const double *freqs, size_t nfreq
     caf_plan *p = s->plan;
     s->freqs.assign(freqs, freqs + nfreq);
     s->one_launch = p->fused && p->rows > 0;
-#ifdef CAF_MEASURE
-    if (p->variant == 1 || p->variant == 2) s->one_launch = false;  // measurement variants keep their own kernels
-#endif
+    if (measure_keeps_own_kernels(p)) s->one_launch = false;
     const size_t esz = elem_size(dtype), rsz = real_size(dtype), in1 = n * esz, rows = nfreq ? nfreq : 1;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     s->o_hay = up(in1);
@@ -1562,17 +1283,17 @@ static int get_host_slot(caf_ctx *c, size_t n, const double *freqs, size_t nfreq
     HCHK(pinned_alloc((void **)&s->h_base, pin_bytes));
     memset(s->h_base, 0, pin_bytes);
     HCHK(hipHostGetDevicePointer((void **)&s->m_base, s->h_base, 0));
-    HCHK(hipMalloc(&s->d_needle, in1 < 16 ? 16 : in1));
-    HCHK(hipMalloc(&s->d_ridx, rows * sizeof(uint64_t)));
-    HCHK(hipMalloc(&s->d_rval, rows * rsz));
-    HCHK(hipMalloc(&s->d_peak, sizeof(caf_peak)));
+    HCHK(dev_alloc(&s->d_needle, in1 < 16 ? 16 : in1));
+    HCHK(dev_alloc(&s->d_ridx, rows * sizeof(uint64_t)));
+    HCHK(dev_alloc(&s->d_rval, rows * rsz));
+    HCHK(dev_alloc(&s->d_peak, sizeof(caf_peak)));
     const size_t spec1 = p->fused ? (size_t)2 * 16 * 256 * esz : (p->chain || p->small) ? p->L * esz : 0;
-    if (spec1) HCHK(hipMalloc(&s->d_spec, spec1 + 256));
+    if (spec1) HCHK(dev_alloc(&s->d_spec, spec1 + 256));
     if (p->chain && p->cR >= 4)
-        HCHK(hipMalloc(&s->d_slab, (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, esz, chain_nb_v(p->clogm, esz)) *
+        HCHK(dev_alloc(&s->d_slab, (size_t)c->cu_count * chain_wg_per_cu_v(p->clogm, esz, chain_nb_v(p->clogm, esz)) *
                                        chain_slab_arrays_v(p->cR) * 16 * (((size_t)1 << p->clogm) / 16) * esz));
     if (s->one_launch) {
-        HCHK(hipMalloc((void **)&s->d_sync, 512));
+        HCHK(dev_alloc((void **)&s->d_sync, 512));
         HCHK(hipMemsetAsync(s->d_sync, 0, 512, c->stream));
         HCHK(hipStreamSynchronize(c->stream));
     }
@@ -1693,11 +1414,7 @@ static int surface_host_impl(caf_ctx *c, const T *needle, const T *hay, size_t n
         p->slab_override = s.d_slab;
         p->stage_out = ho;
         hipError_t e1 = hipSuccess;
-        if (p->fused && in1 % 16 == 0
-#ifdef CAF_MEASURE
-            && p->variant != 2
-#endif
-        ) {  // the spectrum kernel stages the needle in itself
+        if (p->fused && in1 % 16 == 0 && !measure_own_stage_in(p)) {  // the spectrum kernel stages the needle in itself
             p->stage_in_src = s.m_base;
             p->stage_in_dst = s.d_needle;
             p->stage_in_bytes = in1;
@@ -1771,7 +1488,7 @@ extern "C" int caf_host_alloc(caf_ctx *c, size_t bytes, void **out)
     hipError_t e = pinned_alloc(&h, bytes);
     if (e != hipSuccess) return fail(CAF_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
     e = hipHostGetDevicePointer(&m, h, 0);
-    if (e != hipSuccess) { (void)hipHostFree(h); return fail(CAF_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)pin_free(h); return fail(CAF_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
     c->host_ranges[(char *)h] = HostRange{bytes, (char *)m, true};
     *out = h;
     return CAF_OK;
@@ -1803,7 +1520,7 @@ static int host_range_drop(caf_ctx *c, void *ptr, bool owned, const char *who)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->host_ranges.erase(it);
-    if (owned) HIPCHK(hipHostFree(ptr));
+    if (owned) HIPCHK(pin_free(ptr));
     else HIPCHK(hipHostUnregister(ptr));
     return CAF_OK;
 }
@@ -1919,9 +1636,9 @@ static void stream_free(caf_stream *st)
         if (s.exec) (void)hipGraphExecDestroy(s.exec);
         if (s.graph) (void)hipGraphDestroy(s.graph);
         for (void *p : {s.h_needle, s.h_hay, s.h_peak, s.h_ridx, s.h_rval, (void *)s.h_status, (void *)s.h_seq})
-            if (p) (void)hipHostFree(p);
+            if (p) (void)pin_free(p);
         for (void *p : {s.d_needle, s.d_surface, s.d_ridx, s.d_rval, s.d_peak, s.d_spec, s.d_slab, (void *)s.d_sync})
-            if (p) (void)hipFree(p);
+            if (p) (void)dev_free(p);
         if (s.stream && s.own_stream && st->plan) {  // back to the context's pool
             caf_ctx *c = st->plan->ctx;
             for (size_t i = 0; i < c->slot_pool.size(); ++i)
@@ -1993,9 +1710,7 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
     // round (MI355X: 2 slots 45.5 k vs 38.5 k surfaces/s, 3 slots 50 k vs 55 k, 4 slots 52 k vs 58 k).
     const size_t in_flight = (size_t)nslots * (split ? batch : 1);
     const bool two_nodes = (flags & CAF_STREAM_TWO_KERNELS) || (!(flags & CAF_STREAM_ONE_KERNEL) && in_flight > 2);
-#ifdef CAF_MEASURE
-    if (p->variant == 1 || p->variant == 2 || p->dbg) one_launch = false;  // measurement variants keep their own kernels
-#endif
+    if (measure_keeps_own_kernels(p)) one_launch = false;
     const size_t esz = elem_size(p->dtype), rsz = real_size(p->dtype);
     const size_t in1 = p->n * esz, in_bytes = batch * in1;
     const size_t rows = p->rows ? p->rows : 1;
@@ -2073,20 +1788,20 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
             s.stream = st->slots[0].stream;
             s.own_stream = false;
         }
-        if (spec1) SCHK(hipMalloc(&s.d_spec, split ? batch * spec_stride : batch * spec1 + 256));
-        if (slab1) SCHK(hipMalloc(&s.d_slab, (split ? batch : 1) * slab1));
+        if (spec1) SCHK(dev_alloc(&s.d_spec, split ? batch * spec_stride : batch * spec1 + 256));
+        if (slab1) SCHK(dev_alloc(&s.d_slab, (split ? batch : 1) * slab1));
         SCHK(pinned_alloc(&s.h_needle, in_bytes));
         SCHK(pinned_alloc(&s.h_hay, in_bytes));
         SCHK(pinned_alloc(&s.h_peak, batch * sizeof(caf_peak)));
         SCHK(pinned_alloc(&s.h_ridx, ridx_bytes));
         SCHK(pinned_alloc(&s.h_rval, rval_bytes));
-        SCHK(hipMalloc(&s.d_needle, in_bytes));
-        SCHK(hipMalloc(&s.d_ridx, ridx_bytes));
-        SCHK(hipMalloc(&s.d_rval, rval_bytes));
-        SCHK(hipMalloc(&s.d_peak, batch * sizeof(caf_peak)));
-        if (want_surface) SCHK(hipMalloc(&s.d_surface, surf_bytes));
+        SCHK(dev_alloc(&s.d_needle, in_bytes));
+        SCHK(dev_alloc(&s.d_ridx, ridx_bytes));
+        SCHK(dev_alloc(&s.d_rval, rval_bytes));
+        SCHK(dev_alloc(&s.d_peak, batch * sizeof(caf_peak)));
+        if (want_surface) SCHK(dev_alloc(&s.d_surface, surf_bytes));
         if (one_launch) {
-            SCHK(hipMalloc((void **)&s.d_sync, batch * 512));
+            SCHK(dev_alloc((void **)&s.d_sync, batch * 512));
             SCHK(hipMemset(s.d_sync, 0, batch * 512));
             SCHK(pinned_alloc((void **)&s.h_status, 64));
             memset(s.h_status, 0, 64);
@@ -2149,7 +1864,7 @@ extern "C" int caf_stream_create_ex(caf_plan *p, size_t batch, int nslots, int w
                                                       (caf_peak *)dp, ho, sy, m_status, m_seq + first, two_nodes);
         }
         hipError_t e1 = hipSuccess;
-        if (p->fused && p->variant != 2 && inb % 16 == 0) {  // the spectrum kernel stages the needles in itself
+        if (p->fused && !measure_own_stage_in(p) && inb % 16 == 0) {  // the spectrum kernel stages the needles in itself
             p->stage_in_src = jin.src[0];
             p->stage_in_dst = jin.dst[0];
             p->stage_in_bytes = inb;
