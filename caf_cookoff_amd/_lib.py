@@ -22,6 +22,7 @@ CAF_ERR_HIP = 3
 CAF_ERR_NOMEM = 4
 CAF_ERR_NO_DEVICE = 5
 CAF_ERR_STATE = 6
+CAF_ERR_RCCL = 7
 
 CAF_C128 = 0
 CAF_C64 = 1
@@ -31,6 +32,7 @@ CAF_STREAM_SPLIT = 1
 CAF_STREAM_THREE_KERNELS = 2
 CAF_STREAM_TWO_KERNELS = 4
 CAF_STREAM_ONE_KERNEL = 8
+CAF_MULTI_REDUCE_RCCL = 1
 
 
 class CafPeak(ctypes.Structure):
@@ -94,13 +96,37 @@ SYMBOLS = [
     ("caf_stream_wait", _int, [_vp, _int, _pp, _up, _vp]),
     ("caf_stream_surface", _vp, [_vp, _int]),
     ("caf_multi_stream_share", _int, [_sz, _int, _int, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
-    ("caf_multi_stream_create", _int, [ctypes.POINTER(_int), _int, _sz, _dp, _sz, _u32, _int, _int, ctypes.POINTER(_vp)]),
+    ("caf_multi_stream_create", _int, [ctypes.POINTER(_int), _int, _sz, _dp, _sz, _u32, _int, _int, _int, ctypes.POINTER(_vp)]),
     ("caf_multi_stream_devices", _int, [_vp]),
     ("caf_multi_stream_run", _int, [_vp, _vp, _vp, _sz, _pp, _up, _vp]),
+    ("caf_multi_stream_surface", _vp, [_vp, _int, _int]),
+    ("caf_multi_stream_locate", _int, [_vp, _sz, _sz, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_sz),
+                                       ctypes.POINTER(_int)]),
     ("caf_multi_stream_destroy", _int, [_vp]),
+    ("caf_multi_surface_shard", _int, [_sz, _int, _int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    ("caf_multi_surface_reduce", _int, [_pp, _int, _pp]),
+    ("caf_rccl_library", _int, [ctypes.c_char_p]),
+    ("caf_multi_surface_create", _int, [ctypes.POINTER(_int), _int, _sz, _dp, _sz, _u32, _int, ctypes.c_uint, ctypes.POINTER(_vp)]),
+    ("caf_multi_surface_devices", _int, [_vp]),
+    ("caf_multi_surface_worker_info", _int, [_vp, _int, ctypes.POINTER(_int), ctypes.POINTER(_sz), ctypes.POINTER(_sz),
+                                             ctypes.POINTER(ctypes.c_char_p)]),
+    ("caf_multi_surface_run", _int, [_vp, _vp, _vp, _vp, _up, _vp, _pp]),
+    ("caf_multi_surface_run_stats", _int, [_vp, _dp, _pp]),
+    ("caf_multi_surface_timing_begin", _int, [_vp]),
+    ("caf_multi_surface_timing_end", _int, [_vp, _dp, _up]),
+    ("caf_multi_surface_host_alloc", _int, [_vp, _sz, ctypes.POINTER(_vp)]),
+    ("caf_multi_surface_host_free", _int, [_vp, _vp]),
+    ("caf_multi_surface_host_register", _int, [_vp, _vp, _sz]),
+    ("caf_multi_surface_host_unregister", _int, [_vp, _vp]),
+    ("caf_multi_surface_destroy", _int, [_vp]),
+    ("caf_debug_guard_bands", _int, [_sz]),
+    ("caf_debug_check_guards", _int, [ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
 ]
 
 _libs: dict = {}
+
+
+_torch_rccl = None  # torch's own librccl.so, if its HIP runtime was bound first (see _prefer_torch_hip_runtime)
 
 
 def _prefer_torch_hip_runtime() -> None:
@@ -119,7 +145,10 @@ def _prefer_torch_hip_runtime() -> None:
         spec = None
     if not spec or not spec.origin:
         return
+    global _torch_rccl
     libdir = Path(spec.origin).parent / "lib"
+    if (libdir / "librccl.so").exists():
+        _torch_rccl = libdir / "librccl.so"  # built against the runtime bound below: the one RCCL to dlopen in this process
     for name in ("libhsa-runtime64.so", "libamdhip64.so"):
         p = libdir / name
         if p.exists():
@@ -146,6 +175,8 @@ def load(path=None) -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
+    if _torch_rccl is not None:  # CAF_MULTI_REDUCE_RCCL: load the RCCL that matches the HIP runtime of this process
+        lib.caf_rccl_library(str(_torch_rccl).encode())
     _libs[str(path)] = lib
     return lib
 

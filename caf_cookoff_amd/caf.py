@@ -423,17 +423,20 @@ class MultiStream:
 
     PEAK_DTYPE = Stream.PEAK_DTYPE
 
-    def __init__(self, devices: Sequence[int], n: int, freqs_hz, fs: int, dtype: str = "c128", nslots: int = 3):
+    def __init__(self, devices: Sequence[int], n: int, freqs_hz, fs: int, dtype: str = "c128", nslots: int = 3,
+                 want_surface: bool = False):
         self.lib = _lib.load()
         self._h = None
         fr = np.ascontiguousarray(freqs_hz, dtype=np.float64)
         ids = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
         h = ctypes.c_void_p()
         check(self.lib.caf_multi_stream_create(ids, len(devices), int(n), _dptr(fr), len(fr), int(fs),
-                                               {"c128": CAF_C128, "c64": CAF_C64}[dtype], int(nslots), ctypes.byref(h)),
+                                               {"c128": CAF_C128, "c64": CAF_C64}[dtype], int(nslots), int(bool(want_surface)),
+                                               ctypes.byref(h)),
               self.lib)
         self._h = h
         self.n, self.rows, self.ndev = int(n), len(fr), len(devices)
+        self.devices = [int(d) for d in devices]
         self._cdt = np.complex128 if dtype == "c128" else np.complex64
         self._rdt = np.float64 if dtype == "c128" else np.float32
 
@@ -451,6 +454,20 @@ class MultiStream:
                                             ctypes.c_void_p(rval.ctypes.data) if want_rows else None), self.lib)
         return peaks, ridx, rval
 
+    def surface_ptr(self, worker: int, slot: int) -> int:
+        """``caf_multi_stream_surface``: DEVICE address (on ``devices[worker]``) of the slot's slab
+        [8][rows][2n]; 0 if created without surfaces."""
+        return int(self.lib.caf_multi_stream_surface(self._h, int(worker), int(slot)) or 0)
+
+    def locate(self, count: int, pair: int) -> Tuple[int, int, int, bool]:
+        """``caf_multi_stream_locate``: (worker, slot, index in the slab, still resident) of pair ``pair`` after a
+        run over ``count`` pairs."""
+        w, s, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        i = ctypes.c_size_t()
+        check(self.lib.caf_multi_stream_locate(self._h, int(count), int(pair), ctypes.byref(w), ctypes.byref(s), ctypes.byref(i),
+                                               ctypes.byref(r)), self.lib)
+        return w.value, s.value, i.value, bool(r.value)
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.caf_multi_stream_destroy(self._h)
@@ -461,6 +478,129 @@ class MultiStream:
             self.close()
         except Exception:
             pass
+
+
+def multi_surface_shard(nfreq: int, nworkers: int, worker: int) -> Tuple[int, int]:
+    """``caf_multi_surface_shard``: the contiguous rows [begin, end) worker ``worker`` of ``nworkers`` owns.  Host
+    arithmetic only (== :func:`caf_cookoff_amd.shifts.shard_range`)."""
+    a, b = ctypes.c_size_t(), ctypes.c_size_t()
+    lib = _lib.load()
+    check(lib.caf_multi_surface_shard(int(nfreq), int(nworkers), int(worker), ctypes.byref(a), ctypes.byref(b)), lib)
+    return a.value, b.value
+
+
+def multi_surface_reduce(shard_peaks) -> np.ndarray:
+    """``caf_multi_surface_reduce``: find_peak over shard peak records (structured array of ``Stream.PEAK_DTYPE``):
+    largest value, then lowest global row; no GPU needed.  -> one record."""
+    sp = np.ascontiguousarray(shard_peaks, dtype=Stream.PEAK_DTYPE)
+    out = np.zeros(1, dtype=Stream.PEAK_DTYPE)
+    lib = _lib.load()
+    check(lib.caf_multi_surface_reduce(sp.ctypes.data_as(ctypes.POINTER(CafPeak)), len(sp),
+                                       out.ctypes.data_as(ctypes.POINTER(CafPeak))), lib)
+    return out[0]
+
+
+class MultiSurface:
+    """``caf_multi_surface``: the Doppler rows of ONE surface sharded over several devices behind one call -- the
+    reference's threadpool fan-out and join (mod.rs:391-461) with GPUs as the workers (first
+    decomposition).  ``devices`` may repeat an id (several contexts on one GPU); ``rccl=True`` joins the global peak
+    with ncclAllReduce(max) + ncclAllReduce(min key) inside the process (distinct devices only) instead of on the host."""
+
+    PEAK_DTYPE = Stream.PEAK_DTYPE
+
+    def __init__(self, devices: Sequence[int], n: int, freqs_hz, fs: int, dtype: str = "c128", rccl: bool = False, lib=None):
+        self.lib = _lib.load(lib)
+        self._h = None
+        self.freqs = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        ids = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        h = ctypes.c_void_p()
+        check(self.lib.caf_multi_surface_create(ids, len(devices), int(n), _dptr(self.freqs), len(self.freqs), int(fs),
+                                                {"c128": CAF_C128, "c64": CAF_C64}[dtype],
+                                                _lib.CAF_MULTI_REDUCE_RCCL if rccl else 0, ctypes.byref(h)), self.lib)
+        self._h = h
+        self.n, self.rows, self.ndev, self.dtype = int(n), len(self.freqs), len(devices), dtype
+        self._cdt = np.complex128 if dtype == "c128" else np.complex64
+        self._rdt = np.float64 if dtype == "c128" else np.float32
+        self._host = []  # arrays over caf_multi_surface_host_alloc memory (freed with the object)
+
+    def worker_info(self, worker: int):
+        """-> (device, row_begin, row_end, row-kernel name)."""
+        d, a, b = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_size_t()
+        k = ctypes.c_char_p()
+        check(self.lib.caf_multi_surface_worker_info(self._h, int(worker), ctypes.byref(d), ctypes.byref(a), ctypes.byref(b),
+                                                     ctypes.byref(k)), self.lib)
+        return d.value, a.value, b.value, (k.value or b"").decode()
+
+    def host_empty(self, shape, dtype) -> np.ndarray:
+        """``caf_multi_surface_host_alloc``: pinned memory EVERY worker writes in place.  Lives until :meth:`close`."""
+        dt = np.dtype(dtype)
+        nbytes = max(int(np.prod(shape)) * dt.itemsize, 1)
+        p = ctypes.c_void_p()
+        check(self.lib.caf_multi_surface_host_alloc(self._h, nbytes, ctypes.byref(p)), self.lib)
+        buf = (ctypes.c_char * nbytes).from_address(p.value)
+        buf._caf_owner = self  # the array keeps this object (and so the memory) alive
+        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def run(self, needle, haystack, want_surface: bool = True, out: Optional[np.ndarray] = None):
+        """One surface -> (surface[F,2n] | None, row_idx[F], row_val[F], peak record)."""
+        nd = np.ascontiguousarray(needle, dtype=self._cdt)
+        hs = np.ascontiguousarray(haystack, dtype=self._cdt)
+        if nd.shape != (self.n,) or hs.shape != (self.n,):
+            raise AssertionError("assertion failed: a.len() == self.n")  # xcor_rustfft.rs:54-55
+        F = self.rows
+        surf = Engine._surface_out(out, F, self.n, self._rdt) if want_surface else None
+        ridx = np.zeros(F, dtype=np.uint64)
+        rval = np.zeros(F, dtype=self._rdt)
+        peak = np.zeros(1, dtype=self.PEAK_DTYPE)
+        check(self.lib.caf_multi_surface_run(self._h, ctypes.c_void_p(nd.ctypes.data), ctypes.c_void_p(hs.ctypes.data),
+                                             ctypes.c_void_p(surf.ctypes.data) if want_surface else None, _uptr(ridx),
+                                             ctypes.c_void_p(rval.ctypes.data), peak.ctypes.data_as(ctypes.POINTER(CafPeak))),
+              self.lib)
+        return surf, ridx, rval, peak[0]
+
+    def run_stats(self):
+        """Last run: ({'shards_s', 'reduce_s'}, shard peak records[ndev])."""
+        a = (ctypes.c_double * 2)()
+        sp = np.zeros(self.ndev, dtype=self.PEAK_DTYPE)
+        check(self.lib.caf_multi_surface_run_stats(self._h, a, sp.ctypes.data_as(ctypes.POINTER(CafPeak))), self.lib)
+        return {"shards_s": a[0], "reduce_s": a[1]}, sp
+
+    def timing_begin(self):
+        check(self.lib.caf_multi_surface_timing_begin(self._h), self.lib)
+
+    def timing_end(self):
+        """-> (kernel ms total per worker, launches per worker)."""
+        ms = np.zeros(self.ndev, dtype=np.float64)
+        nl = np.zeros(self.ndev, dtype=np.uint64)
+        check(self.lib.caf_multi_surface_timing_end(self._h, _dptr(ms), _uptr(nl)), self.lib)
+        return ms, nl
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.caf_multi_surface_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def debug_guard_bands(nbytes: int, lib=None) -> None:
+    """``caf_debug_guard_bands``: red zones of ``nbytes`` (rounded up to 4 KiB pages) around every allocation the
+    library makes from now on (process-wide; 0 = off)."""
+    L = _lib.load(lib)
+    check(L.caf_debug_guard_bands(int(nbytes)), L)
+
+
+def debug_check_guards(lib=None) -> Tuple[int, int]:
+    """``caf_debug_check_guards`` -> (allocations checked, violations); raises CafError naming the first damaged
+    allocation if any red zone was written."""
+    L = _lib.load(lib)
+    a, b = ctypes.c_size_t(), ctypes.c_size_t()
+    check(L.caf_debug_check_guards(ctypes.byref(a), ctypes.byref(b)), L)
+    return a.value, b.value
 
 
 _default: dict = {}

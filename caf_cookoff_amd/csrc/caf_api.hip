@@ -77,7 +77,8 @@ struct GuardRec {
     size_t bytes = 0, guard = 0;
     int device = 0;
     bool pinned = false;
-    int line = 0;  // allocation site in this file
+    const char *file = "";  // allocation site
+    int line = 0;
 };
 static std::mutex g_guard_mu;
 static std::map<void *, GuardRec> g_guarded;  // user pointer -> record
@@ -92,7 +93,7 @@ static hipError_t raw_pinned_alloc(void **p, size_t bytes)
     return hipHostMalloc(p, bytes, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable);
 }
 
-static hipError_t guarded_alloc(void **p, size_t bytes, bool pinned, int line)
+static hipError_t guarded_alloc(void **p, size_t bytes, bool pinned, const char *file, int line)
 {
     const size_t g = g_guard_bytes.load(std::memory_order_relaxed);
     if (g == 0) return pinned ? raw_pinned_alloc(p, bytes) : hipMalloc(p, bytes);
@@ -110,6 +111,7 @@ static hipError_t guarded_alloc(void **p, size_t bytes, bool pinned, int line)
     }
     GuardRec r;
     r.base = base; r.bytes = bytes; r.guard = g; r.pinned = pinned; r.line = line;
+    r.file = strrchr(file, '/') ? strrchr(file, '/') + 1 : file;
     (void)hipGetDevice(&r.device);
     {
         std::lock_guard<std::mutex> lk(g_guard_mu);
@@ -135,8 +137,8 @@ static hipError_t guarded_free(void *p, bool pinned)
     return pinned ? hipHostFree(p) : hipFree(p);
 }
 
-#define dev_alloc(pp, bytes) guarded_alloc((void **)(pp), (bytes), false, __LINE__)
-#define pinned_alloc(pp, bytes) guarded_alloc((void **)(pp), (bytes), true, __LINE__)
+#define dev_alloc(pp, bytes) guarded_alloc((void **)(pp), (bytes), false, __FILE__, __LINE__)
+#define pinned_alloc(pp, bytes) guarded_alloc((void **)(pp), (bytes), true, __FILE__, __LINE__)
 static hipError_t dev_free(void *p) { return guarded_free(p, false); }
 static hipError_t pin_free(void *p) { return guarded_free(p, true); }
 
@@ -197,7 +199,8 @@ struct HostSlot {
 struct HostRange {  // caller memory this context may write in place (caf_host_alloc / caf_host_register)
     size_t bytes = 0;
     char *dev = nullptr;
-    bool owned = false;
+    bool owned = false;     // caf_host_alloc: freed with the context
+    bool borrowed = false;  // memory of a caf_multi_surface (registered in every worker's context, owned by that object)
 };
 
 struct caf_ctx {
@@ -432,6 +435,7 @@ extern "C" int caf_ctx_destroy(caf_ctx *c)
     c->io_surface.release(); c->io_a.release(); c->io_b.release();
     c->pin_a.release(); c->pin_b.release();
     for (auto &kv : c->host_ranges) {
+        if (kv.second.borrowed) continue;
         if (kv.second.owned) (void)pin_free(kv.first);
         else (void)hipHostUnregister(kv.first);
     }
@@ -1238,35 +1242,22 @@ static void host_slot_free(HostSlot *s)
 
 static constexpr size_t HOST_SLOTS_MAX = 4;
 
-static int get_host_slot(caf_ctx *c, size_t n, const double *freqs, size_t nfreq, uint32_t fs, int dtype, HostSlot **out)
+// A plan over rows [row_begin, row_end) of the freq list + the staging slot the host-pointer calls run it through.
+// (row_begin, row_end) = (0, nfreq) for caf_surface_*; a proper shard for the workers of caf_multi_surface_*.
+static int make_host_slot(caf_ctx *c, size_t n, const double *freqs, size_t nfreq, uint32_t fs, int dtype, size_t row_begin,
+                          size_t row_end, HostSlot **out)
 {
-    for (HostSlot *s : c->host_slots) {
-        const caf_plan *p = s->plan;
-        if (p->n == n && p->fs == fs && p->dtype == dtype && p->nfreq_total == nfreq && s->freqs.size() == nfreq &&
-            (nfreq == 0 || memcmp(s->freqs.data(), freqs, nfreq * sizeof(double)) == 0)) {
-            s->stamp = ++c->host_clock;
-            *out = s;
-            return CAF_OK;
-        }
-    }
-    if (c->host_slots.size() >= HOST_SLOTS_MAX) {  // evict the least recently used
-        size_t lru = 0;
-        for (size_t i = 1; i < c->host_slots.size(); ++i)
-            if (c->host_slots[i]->stamp < c->host_slots[lru]->stamp) lru = i;
-        (void)hipStreamSynchronize(c->stream);
-        host_slot_free(c->host_slots[lru]);
-        c->host_slots.erase(c->host_slots.begin() + (long)lru);
-    }
+    std::vector<double> fcopy(freqs, freqs + nfreq);  // (before anything is allocated: bad_alloc leaks nothing)
     HostSlot *s = new (std::nothrow) HostSlot;
     if (!s) return fail(CAF_ERR_NOMEM, "out of host memory");
     auto bail = [&](int code) { host_slot_free(s); return code; };
-    int rc = caf_plan_create(c, n, freqs, nfreq, fs, dtype, 0, nfreq, &s->plan);
+    int rc = caf_plan_create(c, n, freqs, nfreq, fs, dtype, row_begin, row_end, &s->plan);
     if (rc) return bail(rc);
     caf_plan *p = s->plan;
-    s->freqs.assign(freqs, freqs + nfreq);
+    s->freqs = std::move(fcopy);
     s->one_launch = p->fused && p->rows > 0;
     if (measure_keeps_own_kernels(p)) s->one_launch = false;
-    const size_t esz = elem_size(dtype), rsz = real_size(dtype), in1 = n * esz, rows = nfreq ? nfreq : 1;
+    const size_t esz = elem_size(dtype), rsz = real_size(dtype), in1 = n * esz, rows = p->rows ? p->rows : 1;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     s->o_hay = up(in1);
     s->o_peak = s->o_hay + up(in1);
@@ -1298,6 +1289,33 @@ static int get_host_slot(caf_ctx *c, size_t n, const double *freqs, size_t nfreq
         HCHK(hipStreamSynchronize(c->stream));
     }
 #undef HCHK
+    *out = s;
+    return CAF_OK;
+}
+
+static int get_host_slot(caf_ctx *c, size_t n, const double *freqs, size_t nfreq, uint32_t fs, int dtype, HostSlot **out)
+{
+    for (HostSlot *s : c->host_slots) {
+        const caf_plan *p = s->plan;
+        if (p->n == n && p->fs == fs && p->dtype == dtype && p->nfreq_total == nfreq && s->freqs.size() == nfreq &&
+            (nfreq == 0 || memcmp(s->freqs.data(), freqs, nfreq * sizeof(double)) == 0)) {
+            s->stamp = ++c->host_clock;
+            *out = s;
+            return CAF_OK;
+        }
+    }
+    HostSlot *s = nullptr;
+    int rc = make_host_slot(c, n, freqs, nfreq, fs, dtype, 0, nfreq, &s);
+    if (rc) return rc;  // (a failed creation leaves the cache as it was)
+    c->host_slots.reserve(HOST_SLOTS_MAX + 1);
+    if (c->host_slots.size() >= HOST_SLOTS_MAX) {  // evict the least recently used, now that its replacement exists
+        size_t lru = 0;
+        for (size_t i = 1; i < c->host_slots.size(); ++i)
+            if (c->host_slots[i]->stamp < c->host_slots[lru]->stamp) lru = i;
+        (void)hipStreamSynchronize(c->stream);
+        host_slot_free(c->host_slots[lru]);
+        c->host_slots.erase(c->host_slots.begin() + (long)lru);
+    }
     s->stamp = ++c->host_clock;
     c->host_slots.push_back(s);
     *out = s;
@@ -1370,22 +1388,18 @@ static int poll_seq(const unsigned long long *h_seq, size_t count, unsigned long
     return CAF_OK;
 }
 
+// One surface (or row shard of one) through a staging slot: `surface`, `row_idx`, `row_val` point at the slot's FIRST row
+// (rows = the plan's shard); `peak` is the shard's find_peak record with GLOBAL row positions.
 template <typename T>
-static int surface_host_impl(caf_ctx *c, const T *needle, const T *hay, size_t n, const double *freqs,
-                             size_t nfreq, uint32_t fs, T *surface, uint64_t *row_idx, T *row_val,
-                             caf_peak *peak, int dtype)
+static int host_slot_run(caf_ctx *c, HostSlot &s, const T *needle, const T *hay, T *surface, uint64_t *row_idx, T *row_val,
+                         caf_peak *peak)
 {
-    if (!c || !needle || !hay || !peak) return fail(CAF_ERR_BAD_ARG, "caf_surface: NULL argument");
-    if (!freqs && nfreq) return fail(CAF_ERR_BAD_ARG, "caf_surface: freqs_hz is NULL");
-    if (!is_pow2(n)) return fail(CAF_ERR_LENGTH, "caf_surface: n=%zu is not a power of two >= 1", n);
-    HIPCHK(hipSetDevice(c->device));
-    HostSlot *sp = nullptr;
-    int rc = get_host_slot(c, n, freqs, nfreq, fs, dtype, &sp);
-    if (rc) return rc;
-    HostSlot &s = *sp;
     caf_plan *p = s.plan;
+    const size_t n = p->n, nfreq = p->rows;
+    int rc;
     const size_t L = 2 * n, in1 = n * sizeof(cpx<T>), surf_bytes = nfreq * L * sizeof(T);
     const bool want_surface = surface && nfreq;
+    HIPCHK(hipSetDevice(c->device));
     // where the row kernel stores the surface: the caller's buffer itself, or a device slab + one D2H copy
     void *surf_target = nullptr;
     bool in_place = false;
@@ -1459,6 +1473,21 @@ static int surface_host_impl(caf_ctx *c, const T *needle, const T *hay, size_t n
     return CAF_OK;
 }
 
+template <typename T>
+static int surface_host_impl(caf_ctx *c, const T *needle, const T *hay, size_t n, const double *freqs,
+                             size_t nfreq, uint32_t fs, T *surface, uint64_t *row_idx, T *row_val,
+                             caf_peak *peak, int dtype)
+{
+    if (!c || !needle || !hay || !peak) return fail(CAF_ERR_BAD_ARG, "caf_surface: NULL argument");
+    if (!freqs && nfreq) return fail(CAF_ERR_BAD_ARG, "caf_surface: freqs_hz is NULL");
+    if (!is_pow2(n)) return fail(CAF_ERR_LENGTH, "caf_surface: n=%zu is not a power of two >= 1", n);
+    HIPCHK(hipSetDevice(c->device));
+    HostSlot *sp = nullptr;
+    int rc = get_host_slot(c, n, freqs, nfreq, fs, dtype, &sp);
+    if (rc) return rc;
+    return host_slot_run<T>(c, *sp, needle, hay, surface, row_idx, row_val, peak);
+}
+
 extern "C" int caf_surface_c128(caf_ctx *c, const double *needle, const double *hay, size_t n,
                                 const double *freqs, size_t nfreq, uint32_t fs, double *surface,
                                 uint64_t *row_idx, double *row_val, caf_peak *peak)
@@ -1489,7 +1518,12 @@ extern "C" int caf_host_alloc(caf_ctx *c, size_t bytes, void **out)
     if (e != hipSuccess) return fail(CAF_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
     e = hipHostGetDevicePointer(&m, h, 0);
     if (e != hipSuccess) { (void)pin_free(h); return fail(CAF_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
-    c->host_ranges[(char *)h] = HostRange{bytes, (char *)m, true};
+    try {
+        c->host_ranges[(char *)h] = HostRange{bytes, (char *)m, true, false};
+    } catch (...) {
+        (void)pin_free(h);
+        throw;
+    }
     *out = h;
     return CAF_OK;
     CAF_GUARD_END
@@ -1501,11 +1535,16 @@ extern "C" int caf_host_register(caf_ctx *c, void *ptr, size_t bytes)
     if (!c || !ptr || !bytes) return fail(CAF_ERR_BAD_ARG, "caf_host_register: NULL argument or zero size");
     HIPCHK(hipSetDevice(c->device));
     if (c->host_ranges.count((char *)ptr)) return fail(CAF_ERR_STATE, "caf_host_register: %p is already registered", ptr);
-    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterMapped));
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
     void *m = nullptr;
     hipError_t e = hipHostGetDevicePointer(&m, ptr, 0);
     if (e != hipSuccess) { (void)hipHostUnregister(ptr); return fail(CAF_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
-    c->host_ranges[(char *)ptr] = HostRange{bytes, (char *)m, false};
+    try {
+        c->host_ranges[(char *)ptr] = HostRange{bytes, (char *)m, false, false};
+    } catch (...) {
+        (void)hipHostUnregister(ptr);
+        throw;
+    }
     return CAF_OK;
     CAF_GUARD_END
 }
@@ -1515,17 +1554,29 @@ static int host_range_drop(caf_ctx *c, void *ptr, bool owned, const char *who)
     if (!c) return fail(CAF_ERR_BAD_ARG, "%s: ctx is NULL", who);
     if (!ptr) return CAF_OK;
     auto it = c->host_ranges.find((char *)ptr);
-    if (it == c->host_ranges.end() || it->second.owned != owned)
+    if (it == c->host_ranges.end() || it->second.owned != owned || it->second.borrowed)
         return fail(CAF_ERR_BAD_ARG, "%s: %p did not come from this context's %s", who, ptr, owned ? "caf_host_alloc" : "caf_host_register");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->host_ranges.erase(it);
+    // the range is forgotten only once the runtime has let go of it: after a failed call it is still pinned, still
+    // addressable by the kernels and still released by caf_ctx_destroy
     if (owned) HIPCHK(pin_free(ptr));
     else HIPCHK(hipHostUnregister(ptr));
+    c->host_ranges.erase(it);
     return CAF_OK;
 }
-extern "C" int caf_host_free(caf_ctx *c, void *ptr) { return host_range_drop(c, ptr, true, "caf_host_free"); }
-extern "C" int caf_host_unregister(caf_ctx *c, void *ptr) { return host_range_drop(c, ptr, false, "caf_host_unregister"); }
+extern "C" int caf_host_free(caf_ctx *c, void *ptr)
+{
+    CAF_GUARD_BEGIN
+    return host_range_drop(c, ptr, true, "caf_host_free");
+    CAF_GUARD_END
+}
+extern "C" int caf_host_unregister(caf_ctx *c, void *ptr)
+{
+    CAF_GUARD_BEGIN
+    return host_range_drop(c, ptr, false, "caf_host_unregister");
+    CAF_GUARD_END
+}
 
 // --------------------------------------------------------------- find_peak --
 extern "C" int caf_find_peak(caf_ctx *c, const double *freqs, const uint64_t *row_idx, const double *row_val,
@@ -2118,7 +2169,9 @@ struct MultiWorker {
 };
 struct caf_multi_stream {
     std::vector<MultiWorker> workers;
+    size_t surf1 = 0;  // bytes of one surface (0: created without surfaces)
 };
+static constexpr size_t MULTI_STREAM_BATCH = 8;
 
 extern "C" int caf_multi_stream_destroy(caf_multi_stream *ms)
 {
@@ -2135,7 +2188,7 @@ extern "C" int caf_multi_stream_destroy(caf_multi_stream *ms)
 }
 
 extern "C" int caf_multi_stream_create(const int *device_ids, int ndev, size_t n, const double *freqs_hz, size_t nfreq,
-                                       uint32_t fs, int dtype, int nslots, caf_multi_stream **out)
+                                       uint32_t fs, int dtype, int nslots, int want_surface, caf_multi_stream **out)
 {
     CAF_GUARD_BEGIN
     if (!out || !device_ids || ndev <= 0 || ndev > 64) return fail(CAF_ERR_BAD_ARG, "caf_multi_stream_create: bad device list");
@@ -2148,12 +2201,14 @@ extern "C" int caf_multi_stream_create(const int *device_ids, int ndev, size_t n
         w.device = device_ids[i];
         int rc = caf_ctx_create(w.device, &w.ctx);
         if (!rc) rc = caf_plan_create(w.ctx, n, freqs_hz, nfreq, fs, dtype, 0, nfreq, &w.plan);
-        if (!rc) rc = caf_stream_create(w.plan, 8, nslots, 0, &w.stream);  // eight surfaces per replay: profiles/r03_stream/form_stability.txt
+        // eight surfaces per replay: profiles/r03_stream/form_stability.txt
+        if (!rc) rc = caf_stream_create(w.plan, MULTI_STREAM_BATCH, nslots, want_surface, &w.stream);
         if (rc) {  // g_err of this thread holds the failing call's message
             caf_multi_stream_destroy(ms);
             return rc;
         }
     }
+    ms->surf1 = want_surface ? nfreq * 2 * n * real_size(dtype) : 0;
     *out = ms;
     return CAF_OK;
     CAF_GUARD_END
@@ -2205,3 +2260,93 @@ extern "C" void *caf_stream_surface(caf_stream *st, int slot)
     if (slot_ok(st, slot)) return nullptr;
     return st->slots[slot].d_surface;
 }
+
+// Device address of a worker's slot slab ([8][rows][2n] of the dtype's real type), NULL if the object was created
+// without surfaces.
+extern "C" void *caf_multi_stream_surface(caf_multi_stream *ms, int worker, int slot)
+{
+    if (!ms || worker < 0 || worker >= (int)ms->workers.size()) return nullptr;
+    return caf_stream_surface(ms->workers[(size_t)worker].stream, slot);
+}
+
+// Where the surface of pair `pair` of the last caf_multi_stream_run over `count` pairs lives: pair k went to worker
+// k % ndev as that worker's item j = k / ndev, in replay j / 8 -> slot (j / 8) % nslots, position j % 8 of the slab;
+// *resident = 0 if a later replay of the same run has overwritten that slot since.
+extern "C" int caf_multi_stream_locate(const caf_multi_stream *ms, size_t count, size_t pair, int *worker, int *slot,
+                                       size_t *index, int *resident)
+{
+    CAF_GUARD_BEGIN
+    if (!ms || pair >= count) return fail(CAF_ERR_BAD_ARG, "caf_multi_stream_locate: pair %zu of %zu", pair, count);
+    const size_t nw = ms->workers.size(), w = pair % nw, j = pair / nw;
+    const size_t nslots = ms->workers[w].stream->slots.size();
+    const size_t items = count > w ? (count - w + nw - 1) / nw : 0;
+    const size_t steps = (items + MULTI_STREAM_BATCH - 1) / MULTI_STREAM_BATCH, step = j / MULTI_STREAM_BATCH;
+    if (worker) *worker = (int)w;
+    if (slot) *slot = (int)(step % nslots);
+    if (index) *index = j % MULTI_STREAM_BATCH;
+    if (resident) *resident = step + nslots >= steps;
+    return CAF_OK;
+    CAF_GUARD_END
+}
+
+// ------------------------------------------------------------- debug: red zones --
+extern "C" int caf_debug_guard_bands(size_t bytes)
+{
+    CAF_GUARD_BEGIN
+    if (bytes > ((size_t)64 << 20)) return fail(CAF_ERR_BAD_ARG, "caf_debug_guard_bands: %zu bytes per guard is more than 64 MiB", bytes);
+    g_guard_bytes.store((bytes + 4095) & ~(size_t)4095);  // whole pages: the alignment of every allocation is kept
+    return CAF_OK;
+    CAF_GUARD_END
+}
+
+extern "C" int caf_debug_check_guards(size_t *allocations_checked, size_t *violations)
+{
+    CAF_GUARD_BEGIN
+    size_t checked = 0, bad = 0;
+    std::string first;
+    int saved = 0;
+    (void)hipGetDevice(&saved);
+    std::vector<unsigned char> buf;
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    for (const auto &kv : g_guarded) {
+        const GuardRec &r = kv.second;
+        HIPCHK(hipSetDevice(r.device));
+        HIPCHK(hipDeviceSynchronize());
+        const unsigned char *head, *tail;
+        if (r.pinned) {
+            head = (const unsigned char *)r.base;
+            tail = (const unsigned char *)r.base + r.guard + r.bytes;
+        } else {
+            buf.resize(2 * r.guard);
+            HIPCHK(hipMemcpy(buf.data(), r.base, r.guard, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(buf.data() + r.guard, r.base + r.guard + r.bytes, r.guard, hipMemcpyDeviceToHost));
+            head = buf.data();
+            tail = buf.data() + r.guard;
+        }
+        ++checked;
+        long off = 0;
+        bool hit = false;
+        for (size_t i = r.guard; i-- > 0 && !hit;)  // nearest byte first on the head side
+            if (head[i] != GUARD_FILL) { hit = true; off = -(long)(r.guard - i); }
+        for (size_t i = 0; i < r.guard && !hit; ++i)
+            if (tail[i] != GUARD_FILL) { hit = true; off = (long)(r.bytes + i); }
+        if (hit) {
+            ++bad;
+            if (first.empty()) {
+                char msg[256];
+                snprintf(msg, sizeof msg, "%s allocation of %zu bytes made at %s:%d (device %d) was written at byte offset %ld",
+                         r.pinned ? "pinned" : "device", r.bytes, r.file, r.line, r.device, off);
+                first = msg;
+            }
+        }
+    }
+    (void)hipSetDevice(saved);
+    if (allocations_checked) *allocations_checked = checked;
+    if (violations) *violations = bad;
+    if (bad) return fail(CAF_ERR_STATE, "caf_debug_check_guards: %zu of %zu allocations have a damaged red zone; first: %s", bad, checked, first.c_str());
+    return CAF_OK;
+    CAF_GUARD_END
+}
+
+// ------------------------------------------------ row shards of ONE surface over devices --
+#include "caf_multi.inc"

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CAF_ABI_VERSION 2
+#define CAF_ABI_VERSION 3
 
 enum caf_status {
     CAF_OK = 0,
@@ -41,8 +41,9 @@ enum caf_status {
     CAF_ERR_LENGTH = 2,    /* n == 0 or not a power of two (xcor_rustfft.rs:54-55 assert) */
     CAF_ERR_HIP = 3,       /* a HIP runtime call failed; see caf_last_error_string() */
     CAF_ERR_NOMEM = 4,
-    CAF_ERR_NO_DEVICE = 5, /* no gfx950 device visible / device id out of range */
-    CAF_ERR_STATE = 6      /* call order violated (e.g. stream used after destroy) */
+    CAF_ERR_NO_DEVICE = 5, /* no HIP device visible / device id out of range / the device is not gfx950 (MI355X) */
+    CAF_ERR_STATE = 6,     /* call order violated (e.g. stream used after destroy) */
+    CAF_ERR_RCCL = 7       /* librccl could not be loaded or an RCCL call failed (CAF_MULTI_REDUCE_RCCL only) */
 };
 
 enum caf_dtype {
@@ -98,7 +99,7 @@ int caf_apply_freq_shift_c64(caf_ctx *ctx, const float *in, size_t n,
  * out[k] = sum_m a[(m+k) mod n] * conj(b[m]) = IFFT(FFT(a)*conj(FFT(b))/n)
  * (unnormalised inverse).  Tables are cached inside the context per n, which is
  * what Xcor::new/clone provide.  One kernel launch for n = 2 ... 16384 (complex128:
- * 8192) reading / writing pinned staging copies of a, b, out; radix-2 passes beyond. */
+ * 8192) reading / writing pinned staging copies of a, b, out; radix-16 Stockham passes over HBM beyond. */
 int caf_xcor_c128(caf_ctx *ctx, const double *a, const double *b, size_t n, double *out);
 int caf_xcor_c64(caf_ctx *ctx, const float *a, const float *b, size_t n, float *out);
 
@@ -154,7 +155,7 @@ int caf_plan_create(caf_ctx *ctx, size_t n, const double *freqs_hz, size_t nfreq
 int caf_plan_destroy(caf_plan *plan);
 /* Name of the kernel path the plan selected: "fused4096" (n = 4096), "chain" (every other n
  * from 1024 to 131072 in complex64 / 65536 in complex128: LDS-resident single-pass rows), "small"
- * (n = 1 ... 512: lane-group rows, one launch) or "generic" (anything larger: radix-2 passes over HBM).  The measurement build can
+ * (n = 1 ... 512: lane-group rows, one launch) or "generic" (anything larger: radix-16 Stockham passes over HBM).  The measurement build can
  * also report "tiled65536" (round 1's three-pass n = 32768 form). */
 const char *caf_plan_path(const caf_plan *plan);
 size_t caf_plan_rows(const caf_plan *plan);
@@ -280,11 +281,78 @@ void *caf_stream_surface(caf_stream *st, int slot);
 typedef struct caf_multi_stream caf_multi_stream;
 int caf_multi_stream_share(size_t count, int nworkers, int worker, size_t *first, size_t *stride, size_t *items);
 int caf_multi_stream_create(const int *device_ids, int ndev, size_t n, const double *freqs_hz, size_t nfreq,
-                            uint32_t fs, int dtype, int nslots, caf_multi_stream **out);
+                            uint32_t fs, int dtype, int nslots, int want_surface, caf_multi_stream **out);
 int caf_multi_stream_devices(const caf_multi_stream *ms);
 int caf_multi_stream_run(caf_multi_stream *ms, const void *needles, const void *haystacks, size_t count,
                          caf_peak *peaks, uint64_t *row_idx, void *row_val);
+/* With want_surface != 0 every worker's slots keep their surfaces on the worker's device, as caf_stream_create does
+ * (the reference's row record carries the magnitudes, mod.rs:17-22,156-161): caf_multi_stream_surface is the device
+ * address of a worker's slot slab ([8][rows][2n] of the dtype's real type; NULL without surfaces), and
+ * caf_multi_stream_locate says where pair `pair` of the last run over `count` pairs lives: worker, slot, position in the
+ * slab, and whether it is still resident (a later replay of the same run reuses the slot). */
+void *caf_multi_stream_surface(caf_multi_stream *ms, int worker, int slot);
+int caf_multi_stream_locate(const caf_multi_stream *ms, size_t count, size_t pair, int *worker, int *slot, size_t *index,
+                            int *resident);
 int caf_multi_stream_destroy(caf_multi_stream *ms);
+
+/* ---- Doppler-row shards of ONE surface over several devices (first decomposition) --------------
+ * The reference's fan-out and join live INSIDE the operator: one caf_surface call spreads the rows over pool workers and
+ * returns the joined rows (CafRustFFTThreadpool::caf_surface, mod.rs:391-461; one task per row :404-457), and find_peak
+ * scans the joined rows (:31-42).  Here the workers are GPUs.  Worker r of ndev owns the contiguous rows
+ * [r*nfreq/ndev, (r+1)*nfreq/ndev) of the freq list (caf_multi_surface_shard: the rule by itself, no GPU needed) with its
+ * own context, row-shard plan and staging, driven by its own host thread for the length of a run (worker 0 by the caller's
+ * thread).  An id may repeat (several contexts on one GPU).  Inputs are replicated, the haystack spectrum is computed on
+ * every device, each device writes its rows of `surface` -- in place if that memory came from caf_multi_surface_host_alloc /
+ * _host_register, else through a device slab and one copy per device -- and its rows of row_idx / row_val; there is no
+ * collective on the data path.  `peak` is find_peak over all rows: the largest value, among equal values the lowest global
+ * row (== the reference's first-strictly-greater scan), joined
+ *   flags == 0                 on the host from the ndev shard records (caf_multi_surface_reduce: the rule by itself);
+ *   CAF_MULTI_REDUCE_RCCL      through RCCL inside this process: ncclAllReduce(max) over the shard values, then
+ *                              ncclAllReduce(min) over (global_row << 32 | idx) keys of the shards holding the maximum
+ *                              (RCCL has no MAXLOC), on the workers' streams over xGMI.  Needs distinct device ids
+ *                              (one RCCL rank per GPU).  librccl is dlopen()ed at the first such create
+ *                              (caf_rccl_library names the file; default "librccl.so.1"): the library does not link it.
+ * surface: nfreq x 2n of the dtype's real type or NULL; row_idx / row_val: nfreq entries or NULL; needle / haystack: n
+ * complex of the dtype (host pointers).  Blocks until every result is in host memory.  If workers fail, the call returns
+ * the status of the first failing one (by position) with its message. */
+typedef struct caf_multi_surface caf_multi_surface;
+enum caf_multi_flags { CAF_MULTI_REDUCE_RCCL = 1 };
+int caf_multi_surface_shard(size_t nfreq, int nworkers, int worker, size_t *row_begin, size_t *row_end);
+int caf_multi_surface_reduce(const caf_peak *shard_peaks, int nshards, caf_peak *out);
+int caf_rccl_library(const char *path);
+int caf_multi_surface_create(const int *device_ids, int ndev, size_t n, const double *freqs_hz, size_t nfreq, uint32_t fs,
+                             int dtype, unsigned flags, caf_multi_surface **out);
+int caf_multi_surface_devices(const caf_multi_surface *h);
+/* device id, row shard and row-kernel name of one worker (any pointer may be NULL) */
+int caf_multi_surface_worker_info(const caf_multi_surface *h, int worker, int *device, size_t *row_begin, size_t *row_end,
+                                  const char **kernel_name);
+int caf_multi_surface_run(caf_multi_surface *h, const void *needle, const void *haystack, void *surface,
+                          uint64_t *row_idx, void *row_val, caf_peak *peak);
+/* last run: seconds2 = {fan-out + shards + join of the worker threads, peak reduction}; shard_peaks[ndev] = every
+ * worker's own find_peak record (global row positions); either may be NULL */
+int caf_multi_surface_run_stats(caf_multi_surface *h, double *seconds2, caf_peak *shard_peaks);
+/* HIP-event time of every worker's row kernel between begin and end: kernel_ms_total[ndev], launches[ndev] (n = 4096
+ * plans run a surface as ONE launch and report no separate row-kernel time: launches 0) */
+int caf_multi_surface_timing_begin(caf_multi_surface *h);
+int caf_multi_surface_timing_end(caf_multi_surface *h, double *kernel_ms_total, uint64_t *launches);
+/* host memory EVERY worker may write in place (pinned, portable): the multi-device counterpart of caf_host_alloc /
+ * caf_host_register; released by the matching call or by caf_multi_surface_destroy */
+int caf_multi_surface_host_alloc(caf_multi_surface *h, size_t bytes, void **out);
+int caf_multi_surface_host_free(caf_multi_surface *h, void *ptr);
+int caf_multi_surface_host_register(caf_multi_surface *h, void *ptr, size_t bytes);
+int caf_multi_surface_host_unregister(caf_multi_surface *h, void *ptr);
+int caf_multi_surface_destroy(caf_multi_surface *h);
+
+/* ---- debug: red zones ---------------------------------------------------------------------------------------------
+ * GPU AddressSanitizer is not available for this target, so the library can police its own allocations: after
+ * caf_debug_guard_bands(bytes) every device / pinned allocation the library makes (tables, spectra, slabs, staging, stream
+ * slots, caf_host_alloc memory, ...) is laid out [guard | allocation | guard] with the guards (rounded up to whole 4 KiB
+ * pages) filled with 0xA5; caf_debug_check_guards synchronises every device that holds such an allocation and verifies all
+ * guards of all live allocations: CAF_OK, or CAF_ERR_STATE with the first damaged allocation (size, allocation site, byte
+ * offset of the stray store) in caf_last_error_string().  Process-wide; bytes == 0 switches it off again for later
+ * allocations.  A debugging aid: allocations become slower, kernels do not. */
+int caf_debug_guard_bands(size_t bytes);
+int caf_debug_check_guards(size_t *allocations_checked, size_t *violations);
 
 #ifdef __cplusplus
 }

@@ -193,7 +193,7 @@ class CafHipMultiStream {
         : n_(n)
     {
         check(caf_multi_stream_create(devices.data(), static_cast<int>(devices.size()), n, freqs_hz.data(), freqs_hz.size(), fs,
-                                      CAF_C128, nslots, &ms_),
+                                      CAF_C128, nslots, 0, &ms_),
               "caf_multi_stream_create");
     }
     CafHipMultiStream(const CafHipMultiStream &) = delete;
@@ -220,6 +220,60 @@ class CafHipMultiStream {
   private:
     std::size_t n_;
     caf_multi_stream *ms_ = nullptr;
+};
+
+// `impl CafSurface for CafHipMulti`: ONE caf_surface call whose Doppler rows are sharded over several GPUs inside the
+// operator, like CafRustFFTThreadpool spreads them over pool workers (mod.rs:391-461): worker r computes the contiguous rows
+// [r*F/G, (r+1)*F/G) and writes them into the shared pinned arena in place; find_peak over all rows is joined on the host
+// or, with `rccl`, by ncclAllReduce(max) + ncclAllReduce(min key) over xGMI (distinct devices only).  An instance fixes
+// (devices, n, freq list, fs) the way Xcor::new fixes n; RAII.
+class CafHipMulti {
+  public:
+    CafHipMulti(const std::vector<int> &devices, std::size_t n, const std::vector<double> &freqs_hz, uint32_t fs, bool rccl = false)
+        : n_(n), freqs_(freqs_hz)
+    {
+        check(caf_multi_surface_create(devices.data(), static_cast<int>(devices.size()), n, freqs_hz.data(), freqs_hz.size(), fs,
+                                       CAF_C128, rccl ? CAF_MULTI_REDUCE_RCCL : 0u, &h_),
+              "caf_multi_surface_create");
+        const std::size_t values = freqs_hz.size() * 2 * n;
+        if (values) {
+            void *p = nullptr;
+            if (int rc = caf_multi_surface_host_alloc(h_, values * sizeof(double), &p)) {
+                caf_multi_surface_destroy(h_);
+                check(rc, "caf_multi_surface_host_alloc");
+            }
+            arena_ = static_cast<double *>(p);
+        }
+    }
+    CafHipMulti(const CafHipMulti &) = delete;
+    CafHipMulti &operator=(const CafHipMulti &) = delete;
+    ~CafHipMulti() { caf_multi_surface_destroy(h_); }  // frees the arena too
+    int devices() const { return caf_multi_surface_devices(h_); }
+
+    // mod.rs:26-27: rows in freq-list order; the global (freq, idx) of find_peak comes back in `peak`
+    std::vector<CafSurfaceRow> caf_surface(const std::vector<Complex64> &needle, const std::vector<Complex64> &haystack,
+                                           std::pair<double, std::size_t> *peak = nullptr)
+    {
+        if (needle.size() != n_ || haystack.size() != n_)  // Xcor::run's assert (xcor_rustfft.rs:54-55)
+            throw std::runtime_error("assertion failed: a.len() == self.n");
+        const std::size_t F = freqs_.size(), L = 2 * n_;
+        std::vector<double> val(F);
+        std::vector<uint64_t> idx(F);
+        caf_peak pk;
+        check(caf_multi_surface_run(h_, needle.data(), haystack.data(), arena_, idx.data(), val.data(), &pk), "caf_multi_surface_run");
+        if (peak) *peak = {pk.freq, static_cast<std::size_t>(pk.idx)};
+        std::vector<CafSurfaceRow> rows(F);
+        for (std::size_t r = 0; r < F; ++r)
+            rows[r] = CafSurfaceRow{freqs_[r], std::vector<double>(arena_ + r * L, arena_ + (r + 1) * L),
+                                    static_cast<std::size_t>(idx[r]), val[r]};
+        return rows;
+    }
+
+  private:
+    std::size_t n_;
+    std::vector<double> freqs_;
+    caf_multi_surface *h_ = nullptr;
+    double *arena_ = nullptr;
 };
 
 // utils.rs:10-35: packed LE f32 I/Q pairs -> Complex64

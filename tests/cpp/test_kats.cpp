@@ -134,6 +134,39 @@ int main(int argc, char **argv)
         check(caf_host_free(default_ctx(), pinned), "caf_host_free");
         std::printf("test hip_surface_in_place ... %s\n", failures == before ? "ok" : "FAILED");
     }
+    // `impl CafSurface for CafHipMulti`: the rows of ONE surface sharded over workers inside the operator (the
+    // reference's threadpool shape, mod.rs:391-461), here two and three contexts on GPU 0: every row record and every
+    // surface value equal to the unsharded call's, and the reference's own answers on KAT 0, 2 (tightest margin), 4
+    {
+        struct K { const char *nd, *hs; double a, b, st, f; std::size_t idx; };
+        const K ks[3] = {{"chirp_0_raw.c64", "chirp_0_T+202samp_F+69.25Hz.c64", -100.0, 100.0, 0.25, 69.25, 202},
+                         {"chirp_2_raw.c64", "chirp_2_T+169samp_F+32.16Hz.c64", 30.0, 35.0, 0.05, 32.15, 169},
+                         {"chirp_4_raw.c64", "chirp_4_T+70samp_F+82.89Hz.c64", 80.0, 100.0, 0.1, 82.9, 70}};
+        const int before = failures;
+        for (const K &k : ks) {
+            auto files = load_files(data_dir + k.nd, data_dir + k.hs);
+            auto shifts = gen_float_shifts(k.a, k.b, k.st);
+            auto want = CafHip::caf_surface(files.first, files.second, shifts, 48000);
+            for (int workers = 2; workers <= 3; ++workers) {
+                CafHipMulti multi(std::vector<int>(workers, 0), files.first.size(), shifts, 48000);
+                ASSERT_EQ(multi.devices(), workers);
+                std::pair<double, std::size_t> pk;
+                auto got = multi.caf_surface(files.first, files.second, &pk);
+                ASSERT_EQ(pk.first, k.f);
+                ASSERT_EQ(pk.second, k.idx);
+                ASSERT_EQ(got.size(), want.size());
+                for (std::size_t r = 0; r < want.size() && r < got.size(); ++r) {
+                    ASSERT_EQ(got[r].xcor_peak_idx, want[r].xcor_peak_idx);
+                    ASSERT_EQ(got[r].xcor_peak_val, want[r].xcor_peak_val);
+                    ASSERT_EQ(std::memcmp(got[r].xcor_mag.data(), want[r].xcor_mag.data(), want[r].xcor_mag.size() * sizeof(double)), 0);
+                }
+                auto pk2 = CafHip::find_peak(std::move(got));  // the joined rows scanned like mod.rs:31-42
+                ASSERT_EQ(pk2.first, k.f);
+                ASSERT_EQ(pk2.second, k.idx);
+            }
+        }
+        std::printf("test hip_multi_row_shards ... %s\n", failures == before ? "ok" : "FAILED");
+    }
     std::printf("test result: %s. %d failed\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;
 }
