@@ -334,7 +334,7 @@ def test_red_zones_host_api(n, dtype, nfreq, guards, oracle):
         want = oracle.np_xcor(x.astype(np.complex128), y.astype(np.complex128))
         assert np.max(np.abs(got - want)) <= (1e-9 if dtype == "c128" else 2e-3) * np.max(np.abs(want))
         sh = e.apply_freq_shift(x, 12.5, FS)
-        assert np.max(np.abs(sh - oracle.np_apply_freq_shift_fast(x.astype(np.complex128), 12.5, FS))) <= (1e-12 if dtype == "c128" else 1e-5)
+        assert np.max(np.abs(sh - oracle.np_apply_freq_shift_fast(x.astype(np.complex128), 12.5, FS))) <= (1e-11 if dtype == "c128" else 1e-5)   # (phase argument error grows with the sample index)
         rows = e.caf_surface(x, y, fr, FS, want_surface=False, dtype=dtype)
         assert e.find_peak(rows) == oracle.np_find_peak(fr, oidx, oval)
         if n >= 2:
