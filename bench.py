@@ -87,6 +87,14 @@ def parse_args(argv=None):
                     help="N>1: run step k's peak exchange on a side stream under step k+1's kernels (alternating caf_peak "
                          "buffers): ~2 %% more surfaces/s with ONE rank under RCCL, but no multi-GPU box has run it yet, so the "
                          "default keeps the exchange on the main stream")
+    ap.add_argument("--in-process", action="store_true",
+                    help="ONE process drives all --gpus N devices through the C ABI's caf_multi_surface_* (row shards of one "
+                         "surface on per-device host threads, global peak joined on the host or by in-process RCCL): times "
+                         "BASELINE configs[3] (4096 x 65536 complex64) through it; no torchrun, no torch.distributed")
+    ap.add_argument("--in-process-devices", default=None,
+                    help="--in-process: comma-separated device ids instead of 0..N-1 (ids may repeat, e.g. 0,0 on a one-GPU box)")
+    ap.add_argument("--blocks", type=int, default=10, help="further timed blocks of --steps launches after the reported one "
+                    "(extra.headline_blocks: median / min / max of the step time)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no GPU work: launch + rendezvous + peak reduction + JSON relay on fabricated shard peaks "
                          "(gloo); what the CPU test suite runs")
@@ -298,6 +306,57 @@ class Case:
         self.surf = self.ridx = self.rval = self.peak = self.peak_i = self.nd = self.hs = None
 
 
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "extra")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel",
+                 "kernel_ms", "launches_timed", "algorithmic_bytes_per_launch", "frac_of_achievable_6.29TBs", "whole_step_frac")
+MULTI_EXTRA_KEYS = ("rank_kernel_ms", "rccl_world", "headline_blocks", "configs3_c64_sharded", "configs4_stream_surface_parallel")
+
+
+def assemble_line(args, *, F, n_samp, world, n_gpus_seen, nsurf, rows, K, el, kern_ms, launches, kernel_name, kernel_path,
+                  devname, cu, ndev, peak_exchange):
+    """The ONE place the bench line is put together: the measured run at any N and the --plumbing-only rehearsal (fabricated
+    measurements) go through it, so that every line carries the same keys (tests/test_bench_launch.py compares them).
+    `cpu_baseline` and `extra` are filled in by the caller after the timed region; both keys always exist."""
+    value = nsurf * K / el if el and el > 0 else None
+    abytes = algorithmic_bytes(nsurf, rows, n_samp, args.dtype)
+    roof = roofline_entry(abytes, kern_ms) if kern_ms else {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None}
+    tf = traffic_fields(kernel_name, nsurf, args.dtype, abytes)
+    if tf["traffic"] is None and tf["traffic_source"] is None:
+        tf["traffic_source"] = ("none: no PMC profile of this launch shape (%d surfaces x %d rows per launch) is committed under "
+                                "profiles/" % (nsurf, rows))
+    roof.update(tf)
+    roof.update({"kernel": kernel_name, "kernel_ms": kern_ms, "launches_timed": launches,
+                 "algorithmic_bytes_per_launch": abytes,
+                 "frac_of_achievable_6.29TBs": roof["achieved"] / HBM_ACHIEVABLE_GBS if roof["achieved"] else None,
+                 "whole_step_frac": (abytes * K / el / 1e9) / HBM_PEAK_GBS if el and el > 0 else None})
+    cfg_idx = 3 if n_samp == 32768 else 1 if args.dtype == "c128" else 2
+    return {
+        "metric": "CAF surfaces/sec (400 freqs x 8192 samp, c128)"
+                  if (F == 400 and args.dtype == "c128" and n_samp == N_SAMP)
+                  else f"CAF surfaces/sec ({F} freqs x {2 * n_samp} samp, {args.dtype})",
+        "value": value, "unit": "surfaces/s", "n_gpus": n_gpus_seen, "steps": K, "warmup": args.warmup,
+        "ms_per_step": el / K * 1e3 if K else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64" if args.dtype == "c128" else "f32", "data": "synthetic",
+        "config": {"workload": f"{F}x{2 * n_samp} {'complex128' if args.dtype == 'c128' else 'complex64'} "
+                               f"filterbank CAF (BASELINE configs[{cfg_idx}]), n={n_samp}, fs=48000",
+                   "surfaces_per_step": nsurf, "batch_per_gpu": args.batch,
+                   "rows_per_gpu": rows, "parallelism": f"doppler-row-shard x{world}" if world > 1 else "single",
+                   "peak_exchange": peak_exchange,
+                   "kernel_path": kernel_path, "device": devname, "cus": cu,
+                   "devices_visible_per_rank": ndev, "kernel_source_hash": kernel_source_hash(kernel_name)},
+        "roofline": roof,
+        "cpu_baseline": None,
+        "extra": {},
+    }
+
+
+def block_stats(ms_list):
+    import statistics
+    return {"blocks": len(ms_list), "ms_per_step_median": statistics.median(ms_list) if ms_list else None,
+            "ms_per_step_min": min(ms_list) if ms_list else None, "ms_per_step_max": max(ms_list) if ms_list else None}
+
+
 def roofline_entry(abytes, kern_ms):
     achieved = abytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
@@ -376,7 +435,7 @@ def host_api_times(reps=200):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def stream_run(plan, nd, hs, lags, total, nslots, batch, split, three_kernels=False, native=True):
+def stream_run(plan, nd, hs, lags, total, nslots, batch, split, three_kernels=False, native=True, passes=5):
     """`total` surfaces through a caf_stream.  native: the whole loop is one caf_stream_run call (fill the
     slot's pinned buffers, replay its graph, retire the oldest slot -- in C++, as a compiled host would);
     otherwise the same loop step by step from Python (submit / wait per slot), which adds ~10 us of
@@ -391,11 +450,16 @@ def stream_run(plan, nd, hs, lags, total, nslots, batch, split, three_kernels=Fa
         a = np.tile(nd, (reps, 1))[:total]
         b = np.tile(hs, (reps, 1))[:total]
         want = np.tile(np.asarray(lags), reps)[:total]
-        for rep in range(3):  # first pass warms the graphs up
+        st.run(a, b)  # warms the graphs up
+        times = []
+        for rep in range(passes):
             t0 = time.perf_counter()
             peaks, _, _ = st.run(a, b)
             dt = time.perf_counter() - t0
-            best = dt if best is None or rep == 1 else min(best, dt)
+            times.append(dt)
+        import statistics
+        best = statistics.median(times)  # (the reported figure is the MEDIAN pass; min / max beside it)
+        stream_run.last_spread = {"passes": passes, "value_min": total / max(times), "value_max": total / min(times)}
         ok = int(np.sum(peaks["idx"] == want))
         hs_ = st.run_stats()  # host-thread time of the LAST pass, per surface
         stream_run.last_host_us = {k.replace("_s", "_us_per_surface"): v / total * 1e6 for k, v in hs_.items()}
@@ -462,12 +526,16 @@ def stream_case(eng, torch, freqs, total=1000):
         forms[name] = {"value": v, "us_per_surface": us, "tau_correct": okc}
         if native:
             forms[name]["host_thread"] = dict(getattr(stream_run, "last_host_us", {}))
+            forms[name].update(getattr(stream_run, "last_spread", {}))
     plan.close()
     abytes = algorithmic_bytes(1, 400, N_SAMP, "c128")
     best = "batched8_4slots"
     return {"workload": f"{total} back-to-back 400x8192 complex128 surfaces from host memory, hipGraph replay per slot, "
-                        "stage-in of inputs and stage-out of peaks included, surfaces left on the device (BASELINE configs[4])",
+                        "stage-in of inputs and stage-out of peaks included, surfaces left on the device (BASELINE configs[4]); "
+                        "the kernels read and write mapped pinned host memory in place (no hipMemcpyAsync / copy-engine nodes)",
             "value": forms[best]["value"], "unit": "surfaces/s", "form": best, "forms": forms,
+            "value_is": f"median of {forms[best].get('passes')} passes over the {total} pairs (one more pass before them warms up)",
+            "value_min": forms[best].get("value_min"), "value_max": forms[best].get("value_max"),
             "algorithmic_bytes_per_surface": abytes, "frac": abytes * forms[best]["value"] / 1e9 / HBM_PEAK_GBS}
 
 
@@ -482,16 +550,137 @@ def multi_stream_case(freqs, devices, total=1000):
     reps = (total + 63) // 64
     a, b = np.tile(nd, (reps, 1))[:total], np.tile(hs, (reps, 1))[:total]
     want = np.tile(np.asarray(lags), reps)[:total]
-    ms = caf.MultiStream(devices, N_SAMP, freqs, FS, nslots=3)
-    best = None
-    for rep in range(3):
+    import statistics
+    ms = caf.MultiStream(devices, N_SAMP, freqs, FS, nslots=3, want_surface=True)
+    ms.run(a, b)
+    times = []
+    for rep in range(5):
         t0 = time.perf_counter()
         peaks, _, _ = ms.run(a, b)
-        dt = time.perf_counter() - t0
-        best = dt if best is None or rep == 1 else min(best, dt)
+        times.append(time.perf_counter() - t0)
+    stored = ms.surface_ptr(0, 0) != 0
     ms.close()
+    best = statistics.median(times)
     return {"value": total / best, "unit": "surfaces/s", "workers": len(devices), "slots_per_worker": 3,
-            "tau_correct": f"{int(np.sum(peaks['idx'] == want))}/{total}"}
+            "surfaces_stored": stored, "value_is": "median of 5 passes", "value_min": total / max(times),
+            "value_max": total / min(times), "tau_correct": f"{int(np.sum(peaks['idx'] == want))}/{total}"}
+
+
+def in_process_config3(devices, steps, warmup, forms=("host_join",), check=True):
+    """BASELINE configs[3] (ONE 4096 x 65536 complex64 surface) through the C ABI's caf_multi_surface_*: ONE process, worker r
+    of G = len(devices) computes the Doppler rows [r*4096/G, (r+1)*4096/G) on devices[r] on its own host thread and keeps them
+    in its HBM (CAF_MULTI_SURFACE_ON_DEVICE: the surface stays sharded); inputs are host pointers
+    (2 x 256 KiB staged per call), row peaks and the global (tau, f) come back to the host.  Forms of the join:
+      host_join   the G shard records reduced on the host
+      rccl_join   ncclAllReduce(max) + ncclAllReduce(min key) inside the process over xGMI (distinct devices only)
+    -> {form: {value surfaces/s, ms_per_surface, per-worker row-kernel ms, join seconds, ...}}."""
+    import numpy as np
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.synth import make_batch
+    f3 = np.arange(4096) * 0.05 - 102.4
+    nd, hs, lags, fos = make_batch(1, 32768, FS, seed0=3000, dtype=np.complex64)
+    want_f = f3[np.argmin(np.abs(f3 - fos[0]))]
+    out = {}
+    for form in forms:
+        ms = caf.MultiSurface(devices, 32768, f3, FS, dtype="c64", rccl=(form == "rccl_join"), surface_on_device=True)
+        try:
+            for _ in range(warmup):
+                ms.run(nd[0], hs[0], want_surface=False)
+            ms.timing_begin()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                _, ridx, rval, pk = ms.run(nd[0], hs[0], want_surface=False)
+            el = time.perf_counter() - t0
+            kms, nl = ms.timing_end()
+            stats, shard = ms.run_stats()
+            info = [ms.worker_info(w) for w in range(len(devices))]
+            ok = int(pk["idx"]) == lags[0] and abs(float(pk["freq"]) - want_f) <= 0.05 + 1e-9
+            if check:
+                assert ok, f"in-process configs[3] ({form}): peak ({pk['freq']}, {pk['idx']}) vs plant ({fos[0]}, {lags[0]})"
+            per_worker = [float(k) / max(1, int(c)) for k, c in zip(kms, nl)]
+            ab0 = algorithmic_bytes(1, info[0][2] - info[0][1], 32768, "c64")
+            out[form] = {"value": steps / el, "unit": "surfaces/s", "ms_per_surface": el / steps * 1e3, "steps": steps,
+                         "devices": list(devices), "rows_per_worker": [i[2] - i[1] for i in info],
+                         "worker_kernel_ms": per_worker, "kernel": info[0][3],
+                         "worker0_algorithmic_bytes": ab0,
+                         "worker0_frac": roofline_entry(ab0, per_worker[0])["frac"] if per_worker[0] > 0 else None,
+                         "last_call": {"shards_ms": stats["shards_s"] * 1e3, "join_ms": stats["reduce_s"] * 1e3},
+                         "global_peak_correct": bool(ok), "surface": "kept on the devices (one slab of rows per worker)"}
+        finally:
+            ms.close()
+    return out
+
+
+def cpu_baseline_config3(seconds: float, max_threads: int):
+    """The C restatement of caf_rust on a BOUNDED sample of configs[3]: 64 of the 4096 rows of a 65536-point surface (f64
+    arithmetic: the port has no f32 path), 3 FFTs per row like the reference, thread-per-row; scaled to surfaces/s."""
+    import numpy as np
+    from oracle import caf_oracle as O
+    from caf_cookoff_amd.synth import make_batch
+    info = host_cpu_info()
+    threads = max(1, min(info["nproc_usable"], max_threads))
+    co = O.COracle()
+    nd, hs, _, _ = make_batch(1, 32768, FS, seed0=3000)
+    f3 = (np.arange(4096) * 0.05 - 102.4)[::64]
+    co.caf_surface(nd[0], hs[0], f3[:8], FS, want_surface=True, hoist=False, nthreads=threads)
+    ts, t0 = [], time.perf_counter()
+    while len(ts) < 3 or (time.perf_counter() - t0 < seconds and len(ts) < 20):
+        t1 = time.perf_counter()
+        co.caf_surface(nd[0], hs[0], f3, FS, want_surface=True, hoist=False, nthreads=threads)
+        ts.append(time.perf_counter() - t1)
+    import statistics
+    t64 = statistics.median(ts)
+    return {"value": 1.0 / (t64 * 4096 / len(f3)), "unit": "surfaces/s", "cores": threads, "kind": "port",
+            "sample": f"median of {len(ts)} x ({len(f3)} of the 4096 rows of one 4096x65536 surface, f64, 3 FFTs/row, {threads} threads), "
+                      f"scaled by 4096/{len(f3)}",
+            "ms_per_sample": t64 * 1e3, "host_cpu": info["model"], "host_nproc": info["nproc_online"],
+            "host_nproc_usable": info["nproc_usable"]}
+
+
+def in_process_main(args):
+    """`bench.py --gpus N --in-process`: the row-shard multi-GPU path as a compiled host would drive it -- one process, the
+    C ABI only (no torch.distributed).  Prints ONE JSON line in the contract's format for BASELINE configs[3]."""
+    import caf_cookoff_amd as caf
+    lib = caf.load()
+    devices = [int(x) for x in args.in_process_devices.split(",")] if args.in_process_devices else list(range(args.gpus))
+    ndev = lib.caf_device_count()
+    if ndev <= 0:
+        sys.exit("bench.py needs a GPU (no CPU fallback exists)")
+    if max(devices) >= ndev:
+        sys.exit(f"bench.py --in-process: device {max(devices)} wanted but only {ndev} device(s) are visible")
+    distinct = len(set(devices)) == len(devices)
+    forms = ("host_join", "rccl_join") if distinct else ("host_join",)
+    K = args.steps
+    res_forms = in_process_config3(devices, steps=K, warmup=max(1, args.warmup), forms=forms, check=not args.no_check)
+    head = res_forms["host_join"]
+    eng = caf.Engine(devices[0])
+    cu, devname = eng.device_info()
+    eng.close()
+    kms = head["worker_kernel_ms"]
+    ab = head["worker0_algorithmic_bytes"]
+    roof = roofline_entry(ab, kms[0]) if kms[0] > 0 else {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None}
+    roof.update(traffic_fields(head["kernel"], 1, "c64", ab))
+    if roof["traffic"] is None and roof["traffic_source"] is None:
+        roof["traffic_source"] = f"none: no PMC profile of a {head['rows_per_worker'][0]}-row launch is committed under profiles/"
+    roof.update({"kernel": head["kernel"], "kernel_ms": kms[0], "launches_timed": K, "algorithmic_bytes_per_launch": ab,
+                 "frac_of_achievable_6.29TBs": roof["achieved"] / HBM_ACHIEVABLE_GBS if roof["achieved"] else None,
+                 "whole_step_frac": ab / (head["ms_per_surface"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "of": "worker 0's row shard (every worker launches the same kernel on its own rows)"})
+    res = {"metric": "CAF surfaces/sec (4096 freqs x 65536 samp, c64)", "value": head["value"], "unit": "surfaces/s",
+           "n_gpus": len(set(devices)), "steps": K, "warmup": max(1, args.warmup), "ms_per_step": head["ms_per_surface"],
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "ONE 4096x65536 complex64 filterbank CAF per step (BASELINE configs[3]), Doppler rows sharded over "
+                                  f"{len(devices)} worker(s) inside ONE process through caf_multi_surface_* (host pointers in, peaks out, "
+                                  "surface rows kept in each worker's HBM), n=32768, fs=48000",
+                      "devices": devices, "rows_per_worker": head["rows_per_worker"], "parallelism": f"doppler-row-shard x{len(devices)} (in-process)",
+                      "peak_exchange": "host join of the shard records (value); in-process RCCL join beside it in extra",
+                      "kernel_path": "chain", "device": devname, "cus": cu, "devices_visible": ndev,
+                      "kernel_source_hash": kernel_source_hash(head["kernel"])},
+           "roofline": roof,
+           "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_config3(args.cpu_seconds, args.cpu_threads),
+           "extra": {"forms": res_forms, "worker_kernel_ms": kms}}
+    print(json.dumps(res), flush=True)
+    return 0
 
 
 def multi_gpu_extras(args, eng, torch, dist, dev, rank, world, rehearse, freqs):
@@ -632,13 +821,31 @@ def plumbing_only(args):
                                       "rows_rank0": hi3 - lo3 if rank == 0 else None},
              "configs4_stream_surface_parallel": {"plumbing": True, "pairs_total": int(cnt.item()), "pairs_rank0": items,
                                                   "elapsed_ms_max_over_ranks": float(tmax.item()) * 1e3}}
+    # the line goes through the same assembler as a measured run (fabricated measurements: no kernel ran)
+    kms = torch.tensor([0.5 * (rank + 1)], dtype=torch.float64)
+    allk = [torch.zeros_like(kms) for _ in range(world)] if world > 1 else [kms]
+    if world > 1:
+        dist.all_gather(allk, kms)
+    backend = dist.get_backend() if world > 1 else None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"plumbing_only": True, "n_gpus": n_seen, "steps": args.steps, "value": None,
-                          "ms_per_step": el / max(1, args.steps) * 1e3, "peak_reduce": args.peak_reduce,
-                          "extra": extra}), flush=True)
+        res = assemble_line(args, F=F, n_samp=args.n, world=world, n_gpus_seen=n_seen, nsurf=args.batch * world, rows=hi - lo,
+                            K=args.steps, el=el, kern_ms=None, launches=0,
+                            kernel_name="caf::k_seq_rows<double, 15, caf::SeqIo<double> >", kernel_path="fused4096",
+                            devname="none (plumbing only)", cu=0, ndev=0,
+                            peak_exchange=f"{args.peak_reduce}, on the main stream" if world > 1 else None)
+        res["value"] = None
+        res["plumbing_only"] = True
+        if world > 1:
+            extra.update({"rank_kernel_ms": [float(t.item()) for t in allk], "rccl_world": {"world_size": n_seen, "backend": backend},
+                          "headline_blocks": block_stats([el / max(1, args.steps) * 1e3] * 2)})
+        else:
+            extra = {"headline_blocks": block_stats([el / max(1, args.steps) * 1e3] * 2)}
+        res["extra"] = extra
+        res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(min(args.cpu_seconds, 1.0), args.cpu_threads)
+        print(json.dumps(res), flush=True)
     return 0
 
 
@@ -646,6 +853,8 @@ def plumbing_only(args):
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
+    if args.in_process:
+        sys.exit(in_process_main(args))
     if args.gpus > 1 and env_world is None:
         sys.exit(self_launch(args))
     world = int(env_world or "1")
@@ -795,38 +1004,40 @@ def main():
     kern_ms_total, launches = plan.timing_end()
     el = allreduce_max_time(el)
 
+    kern_ms = kern_ms_total / max(1, launches)
+    # ---- ten further timed blocks of K steps: the spread of the step time, and enough GPU time for a sampler to see ----
+    blocks_ms = []
+    for _ in range(max(0, args.blocks)):
+        sync_all()
+        tb = time.perf_counter()
+        for _ in range(K):
+            step()
+        torch.cuda.synchronize()
+        if coll:
+            dist.barrier()
+            torch.cuda.synchronize()
+        blocks_ms.append(allreduce_max_time(time.perf_counter() - tb) / K * 1e3)
+    # every rank's dominant-kernel time, so that a reader sees that every rank worked
+    rank_kernel_ms = [kern_ms]
+    if coll:
+        tk = torch.tensor([kern_ms], dtype=torch.float64, device="cpu" if rehearse else dev)
+        parts = [torch.zeros_like(tk) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, tk)
+        rank_kernel_ms = [float(t.item()) for t in parts]
+
     res = None
     if rank == 0:
-        value = nsurf * K / el
-        kern_ms = kern_ms_total / max(1, launches)
-        abytes = algorithmic_bytes(nsurf, rows, n_samp, args.dtype)
-        roof = roofline_entry(abytes, kern_ms)
-        tf = traffic_fields(plan.kernel_name, nsurf, args.dtype, abytes) if world == 1 else \
-            {"traffic": None, "traffic_over_algorithmic": None, "traffic_source": None}
-        roof.update(tf)
-        roof.update({
-                     "kernel": plan.kernel_name, "kernel_ms": kern_ms, "launches_timed": launches,
-                     "algorithmic_bytes_per_launch": abytes,
-                     "frac_of_achievable_6.29TBs": roof["achieved"] / HBM_ACHIEVABLE_GBS,
-                     "whole_step_frac": (abytes * K / el / 1e9) / HBM_PEAK_GBS})
-        cfg_idx = 3 if n_samp == 32768 else 1 if args.dtype == "c128" else 2
-        res = {
-            "metric": "CAF surfaces/sec (400 freqs x 8192 samp, c128)"
-                      if (F == 400 and args.dtype == "c128" and n_samp == N_SAMP)
-                      else f"CAF surfaces/sec ({F} freqs x {2 * n_samp} samp, {args.dtype})",
-            "value": value, "unit": "surfaces/s", "n_gpus": n_gpus_seen, "steps": K, "warmup": args.warmup,
-            "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if args.dtype == "c128" else "f32", "data": "synthetic",
-            "config": {"workload": f"{F}x{2 * n_samp} {'complex128' if args.dtype == 'c128' else 'complex64'} "
-                                   f"filterbank CAF (BASELINE configs[{cfg_idx}]), n={n_samp}, fs=48000",
-                       "surfaces_per_step": nsurf, "batch_per_gpu": args.batch,
-                       "rows_per_gpu": rows, "parallelism": f"doppler-row-shard x{world}" if world > 1 else "single",
-                       "peak_exchange": (f"{args.peak_reduce}, {'overlapped on a side stream' if overlap else 'on the main stream'}"
-                                         if coll else None),
-                       "kernel_path": plan.path, "device": devname, "cus": cu,
-                       "devices_visible_per_rank": ndev, "kernel_source_hash": kernel_source_hash(plan.kernel_name)},
-            "roofline": roof,
-        }
+        res = assemble_line(args, F=F, n_samp=n_samp, world=world, n_gpus_seen=n_gpus_seen, nsurf=nsurf, rows=rows, K=K, el=el,
+                            kern_ms=kern_ms, launches=launches, kernel_name=plan.kernel_name, kernel_path=plan.path,
+                            devname=devname, cu=cu, ndev=ndev,
+                            peak_exchange=(f"{args.peak_reduce}, {'overlapped on a side stream' if overlap else 'on the main stream'}"
+                                           if coll else None))
+        res["extra"]["headline_blocks"] = block_stats(blocks_ms)
+        res["extra"]["headline_blocks"]["how"] = (f"{len(blocks_ms)} further blocks of {K} steps after the reported one, each between "
+                                                  "barriers (max over ranks); `value` comes from the reported block only")
+        if coll:
+            res["extra"]["rank_kernel_ms"] = rank_kernel_ms
+            res["extra"]["rccl_world"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend()}
     # ---- live VALU issue ceiling of the shipped instruction stream (n = 4096 shapes) ----
     if rank == 0 and world == 1 and n_samp == N_SAMP and not args.no_ceiling:
         try:
@@ -843,7 +1054,7 @@ def main():
 
     # ---- the other BASELINE configs, same process, after the headline (N = 1 only) ------
     if rank == 0 and world == 1 and not args.no_extra and F == 400 and n_samp == N_SAMP and args.dtype == "c128":
-        extra = {}
+        extra = res["extra"]
         torch.cuda.empty_cache()
 
         def plan_case(name, n, freqs_x, dtype, batch, lo_x, hi_x, steps, warmup, cfg, ceiling=None):
@@ -892,8 +1103,13 @@ def main():
             extra["configs4_stream"]["multi_ctx2_same_gpu"] = multi_stream_case(freqs, [local_rank, local_rank], total=1000)
         except Exception as e:
             extra["error"] = f"{type(e).__name__}: {e}"
+        try:
+            extra["in_process_multi"] = in_process_config3([local_rank], steps=10, warmup=2, forms=("host_join", "rccl_join"))
+            extra["in_process_multi"]["two_contexts_same_gpu"] = in_process_config3(
+                [local_rank, local_rank], steps=10, warmup=2, forms=("host_join",))["host_join"]
+        except Exception as e:
+            extra["in_process_multi"] = {"error": f"{type(e).__name__}: {e}"}
         extra["host_api"] = host_api_times()
-        res["extra"] = extra
 
     # ---- N > 1: the two multi-GPU decompositions of the other configs, all ranks take part ------
     if coll and not args.no_extra and F == 400 and n_samp == N_SAMP and args.dtype == "c128":
@@ -902,14 +1118,19 @@ def main():
         # ever, and the headline measured above would never be printed: after EXTRAS_LIMIT_S rank 0 prints the line
         # without the extras and every rank leaves.
         import threading
+        line_lock = threading.Lock()
+        printed = [False]
 
         def give_up():
-            if rank == 0:
-                res["extra"] = {"error": f"the multi-GPU extras did not finish within {EXTRAS_LIMIT_S} s; "
-                                         "the headline above was measured before them"}
-                res["cpu_baseline"] = None
-                print(json.dumps(res), flush=True)
-            os._exit(0)
+            # (every rank leaves with a non-zero status: a hang in the extras is a failure of the run, but the headline
+            #  measured before them is still reported; the process is ended, never restarted or replaced)
+            with line_lock:
+                if rank == 0 and not printed[0]:
+                    printed[0] = True
+                    res["extra"]["error"] = (f"the multi-GPU extras did not finish within {EXTRAS_LIMIT_S} s; "
+                                             "the headline above was measured before them")
+                    print(json.dumps(res), flush=True)
+                os._exit(3)
 
         watchdog = threading.Timer(EXTRAS_LIMIT_S, give_up)
         watchdog.daemon = True
@@ -918,15 +1139,15 @@ def main():
             ex = multi_gpu_extras(args, eng, torch, dist, dev, rank, world, rehearse, freqs)
         except Exception as e:
             ex = {"error": f"{type(e).__name__}: {e}"}
-        watchdog.cancel()
+        with line_lock:   # from here on the main thread owns the line: a timer that fires now finds `printed` set
+            watchdog.cancel()
+            printed[0] = True
         if rank == 0:
-            res["extra"] = ex
+            res["extra"].update(ex)
 
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.cpu_threads)
-        else:
-            res["cpu_baseline"] = None
+        # the CPU comparator runs on rank 0 at ANY world size, after every timed region (the other ranks wait at the last barrier)
+        res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_seconds, args.cpu_threads)
         print(json.dumps(res), flush=True)
     eng.close()
     if coll:

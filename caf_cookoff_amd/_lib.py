@@ -33,6 +33,7 @@ CAF_STREAM_THREE_KERNELS = 2
 CAF_STREAM_TWO_KERNELS = 4
 CAF_STREAM_ONE_KERNEL = 8
 CAF_MULTI_REDUCE_RCCL = 1
+CAF_MULTI_SURFACE_ON_DEVICE = 2
 
 
 class CafPeak(ctypes.Structure):
@@ -108,6 +109,7 @@ SYMBOLS = [
     ("caf_rccl_library", _int, [ctypes.c_char_p]),
     ("caf_multi_surface_create", _int, [ctypes.POINTER(_int), _int, _sz, _dp, _sz, _u32, _int, ctypes.c_uint, ctypes.POINTER(_vp)]),
     ("caf_multi_surface_devices", _int, [_vp]),
+    ("caf_multi_surface_slab", _vp, [_vp, _int]),
     ("caf_multi_surface_worker_info", _int, [_vp, _int, ctypes.POINTER(_int), ctypes.POINTER(_sz), ctypes.POINTER(_sz),
                                              ctypes.POINTER(ctypes.c_char_p)]),
     ("caf_multi_surface_run", _int, [_vp, _vp, _vp, _vp, _up, _vp, _pp]),

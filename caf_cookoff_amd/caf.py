@@ -508,7 +508,8 @@ class MultiSurface:
 
     PEAK_DTYPE = Stream.PEAK_DTYPE
 
-    def __init__(self, devices: Sequence[int], n: int, freqs_hz, fs: int, dtype: str = "c128", rccl: bool = False, lib=None):
+    def __init__(self, devices: Sequence[int], n: int, freqs_hz, fs: int, dtype: str = "c128", rccl: bool = False,
+                 surface_on_device: bool = False, lib=None):
         self.lib = _lib.load(lib)
         self._h = None
         self.freqs = np.ascontiguousarray(freqs_hz, dtype=np.float64)
@@ -516,7 +517,9 @@ class MultiSurface:
         h = ctypes.c_void_p()
         check(self.lib.caf_multi_surface_create(ids, len(devices), int(n), _dptr(self.freqs), len(self.freqs), int(fs),
                                                 {"c128": CAF_C128, "c64": CAF_C64}[dtype],
-                                                _lib.CAF_MULTI_REDUCE_RCCL if rccl else 0, ctypes.byref(h)), self.lib)
+                                                (_lib.CAF_MULTI_REDUCE_RCCL if rccl else 0)
+                                                | (_lib.CAF_MULTI_SURFACE_ON_DEVICE if surface_on_device else 0),
+                                                ctypes.byref(h)), self.lib)
         self._h = h
         self.n, self.rows, self.ndev, self.dtype = int(n), len(self.freqs), len(devices), dtype
         self._cdt = np.complex128 if dtype == "c128" else np.complex64
@@ -530,6 +533,10 @@ class MultiSurface:
         check(self.lib.caf_multi_surface_worker_info(self._h, int(worker), ctypes.byref(d), ctypes.byref(a), ctypes.byref(b),
                                                      ctypes.byref(k)), self.lib)
         return d.value, a.value, b.value, (k.value or b"").decode()
+
+    def slab_ptr(self, worker: int) -> int:
+        """``caf_multi_surface_slab``: DEVICE address of the worker's rows (``surface_on_device=True``), else 0."""
+        return int(self.lib.caf_multi_surface_slab(self._h, int(worker)) or 0)
 
     def host_empty(self, shape, dtype) -> np.ndarray:
         """``caf_multi_surface_host_alloc``: pinned memory EVERY worker writes in place.  Lives until :meth:`close`."""

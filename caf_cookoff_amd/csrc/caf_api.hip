@@ -1389,21 +1389,25 @@ static int poll_seq(const unsigned long long *h_seq, size_t count, unsigned long
 }
 
 // One surface (or row shard of one) through a staging slot: `surface`, `row_idx`, `row_val` point at the slot's FIRST row
-// (rows = the plan's shard); `peak` is the shard's find_peak record with GLOBAL row positions.
+// (rows = the plan's shard); `peak` is the shard's find_peak record with GLOBAL row positions.  `dev_surface` (device
+// memory of this context's GPU, rows x 2n) replaces `surface`: the rows stay on the device.
 template <typename T>
 static int host_slot_run(caf_ctx *c, HostSlot &s, const T *needle, const T *hay, T *surface, uint64_t *row_idx, T *row_val,
-                         caf_peak *peak)
+                         caf_peak *peak, T *dev_surface = nullptr)
 {
     caf_plan *p = s.plan;
     const size_t n = p->n, nfreq = p->rows;
     int rc;
     const size_t L = 2 * n, in1 = n * sizeof(cpx<T>), surf_bytes = nfreq * L * sizeof(T);
-    const bool want_surface = surface && nfreq;
+    const bool want_surface = (surface || dev_surface) && nfreq;
     HIPCHK(hipSetDevice(c->device));
     // where the row kernel stores the surface: the caller's buffer itself, or a device slab + one D2H copy
     void *surf_target = nullptr;
     bool in_place = false;
-    if (want_surface) {
+    if (want_surface && dev_surface) {
+        surf_target = dev_surface;
+        in_place = true;
+    } else if (want_surface) {
         surf_target = host_range_dev(c, surface, surf_bytes);
         in_place = surf_target != nullptr;
         if (!in_place) {

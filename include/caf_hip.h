@@ -316,13 +316,20 @@ int caf_multi_stream_destroy(caf_multi_stream *ms);
  * complex of the dtype (host pointers).  Blocks until every result is in host memory.  If workers fail, the call returns
  * the status of the first failing one (by position) with its message. */
 typedef struct caf_multi_surface caf_multi_surface;
-enum caf_multi_flags { CAF_MULTI_REDUCE_RCCL = 1 };
+enum caf_multi_flags {
+    CAF_MULTI_REDUCE_RCCL = 1,
+    /* every worker keeps its rows of the surface in its own HBM ("the surface stays sharded, no gather on
+     * the timed path"): caf_multi_surface_run takes surface = NULL and caf_multi_surface_slab(h, worker) is the device
+     * address of rows [row_begin, row_end) x 2n on that worker's GPU */
+    CAF_MULTI_SURFACE_ON_DEVICE = 2
+};
 int caf_multi_surface_shard(size_t nfreq, int nworkers, int worker, size_t *row_begin, size_t *row_end);
 int caf_multi_surface_reduce(const caf_peak *shard_peaks, int nshards, caf_peak *out);
 int caf_rccl_library(const char *path);
 int caf_multi_surface_create(const int *device_ids, int ndev, size_t n, const double *freqs_hz, size_t nfreq, uint32_t fs,
                              int dtype, unsigned flags, caf_multi_surface **out);
 int caf_multi_surface_devices(const caf_multi_surface *h);
+void *caf_multi_surface_slab(caf_multi_surface *h, int worker);
 /* device id, row shard and row-kernel name of one worker (any pointer may be NULL) */
 int caf_multi_surface_worker_info(const caf_multi_surface *h, int worker, int *device, size_t *row_begin, size_t *row_end,
                                   const char **kernel_name);

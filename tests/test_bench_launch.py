@@ -27,7 +27,7 @@ def test_self_launch_two_ranks_plumbing_only():
         assert r.returncode == 0, r.stderr[-2000:]
         lines = _json_lines(r.stdout)
         assert len(lines) == 1, r.stdout                     # exactly ONE line, from rank 0
-        assert lines[0]["n_gpus"] == 2 and lines[0]["plumbing_only"] and lines[0]["peak_reduce"] == method
+        assert lines[0]["n_gpus"] == 2 and lines[0]["plumbing_only"] and lines[0]["config"]["peak_exchange"].startswith(method)
         # the N > 1 line carries BOTH multi-GPU decompositions of the other configs: configs[3] as Doppler-row
         # shards of one surface + peak reduction, configs[4] as whole surfaces round-robin over the ranks
         ex = lines[0]["extra"]
@@ -37,8 +37,33 @@ def test_self_launch_two_ranks_plumbing_only():
 
 
 def test_single_rank_plumbing_needs_no_launcher():
-    r = _run(["--plumbing-only", "--steps", "2"])
+    r = _run(["--plumbing-only", "--steps", "2", "--no-cpu-baseline"])
     assert r.returncode == 0 and _json_lines(r.stdout)[0]["n_gpus"] == 1
+
+
+def test_n2_line_has_the_keys_of_the_n1_line():
+    """Every bench line is put together by bench.assemble_line -- the measured run at any N and this rehearsal with
+    fabricated measurements -- so the N = 2 line must carry exactly the N = 1 line's keys (the contract's keys + `roofline`
+    + `cpu_baseline` + `extra`), a `cpu_baseline` object measured on rank 0 at N = 2 too, a `traffic` field that is null only
+    with a stated reason, and the per-rank evidence that every rank worked."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    r1 = _run(["--plumbing-only", "--steps", "2", "--cpu-seconds", "0.5"])
+    r2 = _run(["--gpus", "2", "--plumbing-only", "--steps", "2", "--cpu-seconds", "0.5"])
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stderr[-1000:] + r2.stderr[-1000:]
+    l1, l2 = _json_lines(r1.stdout)[0], _json_lines(r2.stdout)[0]
+    assert set(l1) == set(l2) == set(bench.LINE_KEYS) | {"plumbing_only"}
+    assert set(l1["roofline"]) == set(l2["roofline"]) == set(bench.ROOFLINE_KEYS)
+    assert set(l1["config"]) == set(l2["config"])
+    for line in (l1, l2):
+        cb = line["cpu_baseline"]
+        assert cb and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb and cb["unit"] == "surfaces/s"
+        roof = line["roofline"]
+        assert roof["traffic"] is not None or (roof["traffic_source"] or "").startswith("none:")
+        assert line["extra"]["headline_blocks"]["blocks"] >= 1
+    assert set(bench.MULTI_EXTRA_KEYS) <= set(l2["extra"])
+    assert len(l2["extra"]["rank_kernel_ms"]) == 2 and l2["extra"]["rccl_world"]["world_size"] == 2
+    assert l2["config"]["parallelism"] == "doppler-row-shard x2" and l1["config"]["parallelism"] == "single"
 
 
 def test_world_size_mismatch_is_an_error():
