@@ -101,6 +101,31 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------ the line --
+# Rank 0 prints ONE JSON line on stdout -- and nothing else may reach stdout: libraries under this process (RCCL prints a
+# version banner on fd 1 at communicator creation, the HIP runtime prints diagnostics) write to the process's fd 1
+# directly.  So the real stdout is put aside at start-up, fd 1 is pointed at stderr for everything that runs in between,
+# and emit_line() writes the one line to the saved descriptor.
+_REAL_STDOUT = None
+
+
+def guard_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, data)
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 # ----------------------------------------------------------------------------- launcher --
 def free_port() -> int:
     with socket.socket() as s:
@@ -679,7 +704,7 @@ def in_process_main(args):
            "roofline": roof,
            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_config3(args.cpu_seconds, args.cpu_threads),
            "extra": {"forms": res_forms, "worker_kernel_ms": kms}}
-    print(json.dumps(res), flush=True)
+    emit_line(res)
     return 0
 
 
@@ -845,7 +870,7 @@ def plumbing_only(args):
             extra = {"headline_blocks": block_stats([el / max(1, args.steps) * 1e3] * 2)}
         res["extra"] = extra
         res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(min(args.cpu_seconds, 1.0), args.cpu_threads)
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     return 0
 
 
@@ -853,10 +878,11 @@ def plumbing_only(args):
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None and not args.in_process:
+        sys.exit(self_launch(args))   # (the ranks are children that inherit this stdout; this process prints nothing)
+    guard_stdout()
     if args.in_process:
         sys.exit(in_process_main(args))
-    if args.gpus > 1 and env_world is None:
-        sys.exit(self_launch(args))
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1129,7 +1155,7 @@ def main():
                     printed[0] = True
                     res["extra"]["error"] = (f"the multi-GPU extras did not finish within {EXTRAS_LIMIT_S} s; "
                                              "the headline above was measured before them")
-                    print(json.dumps(res), flush=True)
+                    emit_line(res)
                 os._exit(3)
 
         watchdog = threading.Timer(EXTRAS_LIMIT_S, give_up)
@@ -1148,7 +1174,7 @@ def main():
     if rank == 0:
         # the CPU comparator runs on rank 0 at ANY world size, after every timed region (the other ranks wait at the last barrier)
         res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_seconds, args.cpu_threads)
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     eng.close()
     if coll:
         dist.barrier()
