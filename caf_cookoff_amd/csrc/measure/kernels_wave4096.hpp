@@ -259,7 +259,8 @@ __global__ __launch_bounds__(64, 1) void k_wave_prepare(const FusedArgs<T> A)
     }
 }
 
-template <typename T>
+// AUX: cache policy of the surface stores (CAF_AUX_SC1 = write-through like the workgroup kernels, 0 = default)
+template <typename T, int AUX = CAF_AUX_SC1>
 __global__ __launch_bounds__(64, 1) void k_wave_rows(const FusedArgs<T> A, const cpx<T> *__restrict__ phasor)
 {
     using C = cpx<T>;
@@ -326,8 +327,8 @@ __global__ __launch_bounds__(64, 1) void k_wave_rows(const FusedArgs<T> A, const
             pair_xor1(mlo[2 * j], mlo[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dlo);
             pair_xor1(mhi[2 * j], mhi[2 * j + 1], EVEN_LANES, ~EVEN_LANES, dhi);
             const int m = mpair + 64 * (2 * j + (odd ? 1 : 0));
-            store_vec_aux<CAF_AUX_SC1>(rs, (unsigned)(m * sizeof(T)), dlo);
-            store_vec_aux<CAF_AUX_SC1>(rs, (unsigned)((m + F_N) * sizeof(T)), dhi);
+            store_vec_aux<AUX>(rs, (unsigned)(m * sizeof(T)), dlo);
+            store_vec_aux<AUX>(rs, (unsigned)((m + F_N) * sizeof(T)), dhi);
         }
         T bv = bv_lo;
         uint32_t bi = bv_lo > T(0) ? (uint32_t)(lane + 64 * bi_lo) : 0u;

@@ -537,3 +537,45 @@ def test_bench_launch_shape_vs_oracle(eng, oracle, coracle):
             assert np.max(np.abs(got - osurf)) <= TOL64 * oval.max(), f"surface {b}"
             assert np.array_equal(gi[b][rsel], np.argmax(got, axis=1))
     plan.close()
+
+
+# ------------------------------------------------------ one wave per row (measured and rejected; measurement library) --
+def test_wave_row_kernel_variant_vs_oracle(oracle, monkeypatch):
+    """k_wave_rows<float> (measure/kernels_wave4096.hpp, CAF_ROW_KERNEL=4): the structural attempt of round 4 stays in the
+    measurement library only -- and stays correct: 400 x 8192 complex64 surfaces against the ORACLE within 1e-3 of the
+    maximum, peaks exact, ragged shard, batch beyond the resident waves; complex128 plans ignore the switch."""
+    import torch
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.synth import make_batch
+    if not caf.MEASURE_LIB_PATH.exists():
+        pytest.skip("measurement library not built")
+    monkeypatch.setenv("CAF_ROW_KERNEL", "4")
+    eng = caf.Engine(0, lib=caf.MEASURE_LIB_PATH)
+    try:
+        fr = caf.bench_shifts()
+        B = 5
+        nd, hs, lags, _ = make_batch(B, 4096, FS, seed0=6100, dtype=np.complex64)
+        for lo, hi in ((0, 400), (7, 390)):
+            plan = eng.plan(4096, fr, FS, dtype="c64", row_begin=lo, row_end=hi)
+            assert plan.kernel_name == "caf::k_wave_rows<float>"
+            rows = hi - lo
+            dn, dh = torch.from_numpy(nd).cuda(), torch.from_numpy(hs).cuda()
+            ds = torch.empty((B, rows, 8192), dtype=torch.float32, device="cuda")
+            di = torch.zeros((B, rows), dtype=torch.int64, device="cuda")
+            dv = torch.zeros((B, rows), dtype=torch.float32, device="cuda")
+            dp = torch.zeros((B, 4), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            plan.surface_dev(dn.data_ptr(), dh.data_ptr(), B, ds.data_ptr(), di.data_ptr(), dv.data_ptr(), dp.data_ptr())
+            torch.cuda.synchronize()
+            pk = dp.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[:, 0]
+            for b in range(B):
+                osurf, oidx, oval = oracle.np_caf_surface(nd[b].astype(np.complex128), hs[b].astype(np.complex128), fr[lo:hi], FS)
+                assert np.max(np.abs(ds[b].cpu().numpy() - osurf)) <= TOL32 * osurf.max()
+                of, oi = oracle.np_find_peak(fr[lo:hi], oidx, oval)
+                assert (pk["freq"][b], int(pk["idx"][b])) == (of, oi) and oi == lags[b]
+            plan.close()
+        p128 = eng.plan(4096, fr, FS, dtype="c128")
+        assert "k_seq_rows<double" in p128.kernel_name
+        p128.close()
+    finally:
+        eng.close()

@@ -16,7 +16,7 @@ sys.path.insert(0, str(ROOT))
 FS = 48000
 
 
-def run_variant(variant, nd, hs, fr, batch_time=256, steps=10):
+def run_variant(variant, nd, hs, fr, batch_time=256, steps=10, surface=True):
     import torch
     import caf_cookoff_amd as caf
     os.environ["CAF_ROW_KERNEL"] = str(variant)
@@ -45,11 +45,11 @@ def run_variant(variant, nd, hs, fr, batch_time=256, steps=10):
     tv = torch.zeros((batch_time, F), dtype=torch.float32, device="cuda")
     tp = torch.zeros((batch_time, 4), dtype=torch.float64, device="cuda")
     for _ in range(3):
-        plan.surface_dev(tn.data_ptr(), th.data_ptr(), batch_time, ts.data_ptr(), ti.data_ptr(), tv.data_ptr(), tp.data_ptr())
+        plan.surface_dev(tn.data_ptr(), th.data_ptr(), batch_time, ts.data_ptr() if surface else None, ti.data_ptr(), tv.data_ptr(), tp.data_ptr())
     torch.cuda.synchronize()
     plan.timing_begin()
     for _ in range(steps):
-        plan.surface_dev(tn.data_ptr(), th.data_ptr(), batch_time, ts.data_ptr(), ti.data_ptr(), tv.data_ptr(), tp.data_ptr())
+        plan.surface_dev(tn.data_ptr(), th.data_ptr(), batch_time, ts.data_ptr() if surface else None, ti.data_ptr(), tv.data_ptr(), tp.data_ptr())
     ms, nl = plan.timing_end()
     plan.close()
     eng.close()
@@ -86,7 +86,14 @@ def main():
     ok["max_rel_err_vs_oracle"] = worst
     ok["max_rel_diff_vs_duo"] = float(np.max(np.abs(s4 - s3)) / s3.max())
     assert worst <= 1e-3 and ok["deterministic"]
-    out = {"parity": ok, "kernel_ms_batch256": rep,
+    # variations of the one-wave kernel: default-policy stores, no surface stores at all
+    extra = {}
+    os.environ["CAF_WAVE_STORE"] = "0"
+    extra["default_policy_stores_ms"] = run_variant(4, nd, hs, fr)[2]
+    os.environ.pop("CAF_WAVE_STORE")
+    extra["no_surface_ms"] = run_variant(4, nd, hs, fr, surface=False)[2]
+    extra["duo_no_surface_ms"] = run_variant(3, nd, hs, fr, surface=False)[2]
+    out = {"parity": ok, "kernel_ms_batch256": rep, "variations": extra,
            "surfaces_per_s": {k: [256 / (m * 1e-3) for m in v] for k, v in rep.items()}}
     print(json.dumps(out, indent=1))
 
