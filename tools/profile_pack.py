@@ -16,6 +16,25 @@ for f in glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv")):
     shutil.copy(f, dst / "kernel_stats.csv")
 if (src / "stats_bench.json").exists():
     shutil.copy(src / "stats_bench.json", dst / "bench_under_rocprof.json")
+# steady-state timing of the dominant kernel from the per-dispatch trace: the --stats average includes the warm-up launches
+# (cold caches, first-touch of the output pages), so the median of the launches AFTER the warm-up is stored beside it
+bench_line = json.loads((src / "stats_bench.json").read_text()) if (src / "stats_bench.json").exists() else {}
+durs = []
+for f in glob.glob(str(src / "stats" / "*" / "*kernel_trace.csv")):
+    rows = [r for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    durs += [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+if durs:
+    import statistics
+    warm = min(int(bench_line.get("warmup", 0)), max(0, len(durs) - 1))
+    steady = durs[warm:]
+    timing = {"kernel": kernel, "calls": len(durs), "warmup_calls_dropped": warm,
+              "steady_state_median_ms": statistics.median(steady), "steady_state_min_ms": min(steady),
+              "steady_state_max_ms": max(steady), "average_all_calls_ms": sum(durs) / len(durs),
+              "note": "rocprofv3 --kernel-trace per-dispatch durations of the same command; kernel_stats.csv holds the "
+                      "tool's own average over ALL calls (warm-up included)"}
+    (dst / "kernel_timing.json").write_text(json.dumps(timing, indent=1) + "\n")
+    print(json.dumps(timing))
 files = sorted(glob.glob(str(src / "pmc_*" / "*" / "*counter_collection.csv")))
 out = subprocess.run([sys.executable, str(Path(__file__).parent / "pmc_summary.py"), *files], capture_output=True,
                      text=True).stdout.replace(str(src) + "/", "")

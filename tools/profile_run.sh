@@ -10,12 +10,12 @@ B="$PWD/bench.py"
 mkdir -p "$O"
 export TMPDIR=/tmp
 python3 "$B" --no-extra "${EXTRA[@]}" > "$O/bench_default.json" 2>/dev/null || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$B" --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-ceiling "${EXTRA[@]}" > "$O/stats_bench.json" 2>/dev/null || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$B" --steps 20 --warmup 3 --blocks 0 --no-cpu-baseline --no-extra --no-ceiling "${EXTRA[@]}" > "$O/stats_bench.json" 2>/dev/null || exit 2
 for grp in "pmc_fetch FETCH_SIZE" "pmc_write WRITE_SIZE" \
            "pmc_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "pmc_sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
     set -- $grp
     d=$1; shift
-    rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$O/$d" -- python3 "$B" --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-ceiling "${EXTRA[@]}" > /dev/null 2>&1 || exit 3
+    rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$O/$d" -- python3 "$B" --steps 5 --warmup 2 --blocks 0 --no-cpu-baseline --no-extra --no-ceiling "${EXTRA[@]}" > /dev/null 2>&1 || exit 3
     echo "done $d"
 done
