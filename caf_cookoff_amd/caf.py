@@ -56,6 +56,7 @@ class Engine:
     def __init__(self, device: int = 0, lib=None):
         self._h = None
         self._plans = weakref.WeakSet()
+        self._host_bufs = weakref.WeakSet()   # live host_empty() buffers: close() refuses while any of them is alive
         self.lib = _lib.load(lib)
         h = ctypes.c_void_p()
         self._check(self.lib.caf_ctx_create(int(device), ctypes.byref(h)))
@@ -67,8 +68,14 @@ class Engine:
 
     def close(self):
         """Closes every live Plan (and their Streams) first: caf_ctx_destroy frees the plans'
-        device buffers, so their Python handles must not outlive it."""
+        device buffers, so their Python handles must not outlive it.  Refuses (RuntimeError) while an array of
+        :meth:`host_empty` is still alive: caf_ctx_destroy frees that pinned memory, and a later read or write of the
+        array would touch freed memory -- drop the arrays (and their views) first."""
         if getattr(self, "_h", None):
+            alive = len(self._host_bufs)
+            if alive:
+                raise RuntimeError(f"Engine.close(): {alive} host_empty() array(s) still alive; delete them (and every "
+                                   "view of them) before closing the engine that owns their memory")
             for p in list(self._plans):
                 p.close()
             self._check(self.lib.caf_ctx_destroy(self._h))
@@ -103,18 +110,18 @@ class Engine:
         """``caf_host_alloc``: an uninitialised numpy array in pinned host memory of this context.
         Passed as ``out=`` to :meth:`surface_arrays` the row kernel stores the surface straight into it
         (no device-to-host copy after the kernel).  The memory lives until the array (and every view of
-        it) is garbage-collected or the Engine is closed -- do not touch it after ``close()``."""
+        it) is garbage-collected; the array keeps its Engine alive, and ``close()`` refuses while it exists."""
         dt = np.dtype(dtype)
         nbytes = int(np.prod(shape)) * dt.itemsize
         p = ctypes.c_void_p()
         self._check(self.lib.caf_host_alloc(self._h, max(nbytes, 1), ctypes.byref(p)))
         buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
-        lib, eng_ref, addr = self.lib, weakref.ref(self), p.value
+        buf._caf_owner = self  # the buffer keeps the Engine alive: its context owns (and would free) this memory
+        self._host_bufs.add(buf)
+        lib, h, addr = self.lib, self._h, p.value
 
-        def _free():
-            e = eng_ref()
-            if e is not None and getattr(e, "_h", None):
-                lib.caf_host_free(e._h, ctypes.c_void_p(addr))
+        def _free():   # (h stays valid: the Engine cannot be closed or collected while the buffer lives)
+            lib.caf_host_free(h, ctypes.c_void_p(addr))
         weakref.finalize(buf, _free)
         return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 

@@ -320,8 +320,7 @@ def test_red_zones_host_api(n, dtype, nfreq, guards, oracle):
     fr = np.linspace(-80.0, 80.0, nfreq) if nfreq > 1 else np.array([12.5])
     x, y = _planted(rng, n, FS, float(fr[nfreq // 2]), min(9, n // 4), cdt)
     osurf, oidx, oval = oracle.np_caf_surface(x.astype(np.complex128), y.astype(np.complex128), fr, FS)
-    e = caf.Engine(0)
-    try:
+    def body(e):
         pinned = e.host_empty((nfreq, 2 * n), rdt)
         for out in (None, pinned):
             surf, ridx, rval, pk = e.surface_arrays(x, y, fr, FS, dtype=dtype, out=out)
@@ -345,7 +344,10 @@ def test_red_zones_host_api(n, dtype, nfreq, guards, oracle):
             vp[:] = surf
             assert np.array_equal(e.surface_view(vp, "go"), e.surface_view(surf, "go"))
         _check_guards(caf, min_allocs=3)
-        del pinned
+
+    e = caf.Engine(0)
+    try:
+        body(e)          # (its pinned arrays die with the call: the engine refuses to close under live host_empty() memory)
     finally:
         e.close()
 
@@ -579,3 +581,22 @@ def test_wave_row_kernel_variant_vs_oracle(oracle, monkeypatch):
         p128.close()
     finally:
         eng.close()
+
+
+def test_engine_close_refuses_under_live_host_memory():
+    """Engine.host_empty arrays keep their Engine alive, and close() refuses while one of them exists (the context owns the
+    pinned memory under the array: closing would turn every later access into a use-after-free)."""
+    import gc
+    import caf_cookoff_amd as caf
+    e = caf.Engine(0)
+    a = e.host_empty((4, 8), np.float64)
+    view = a[1:3]
+    with pytest.raises(RuntimeError, match="still alive"):
+        e.close()
+    del a
+    with pytest.raises(RuntimeError):   # a view keeps the buffer alive too
+        e.close()
+    view[:] = 1.0                       # ... and the memory is still there
+    del view
+    gc.collect()
+    e.close()
