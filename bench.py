@@ -270,6 +270,12 @@ def cpu_baseline(seconds: float, max_threads: int):
         "flavours": figs,
         "host_cpu": info["model"], "host_nproc": info["nproc_online"], "host_nproc_usable": info["nproc_usable"],
         "published_reference_ms": {"rust RustFFT 1 thread (R9-3900X)": 177, "rust RustFFT threadpool (R9-3900X)": 28},
+        "corresponds_to": {"value": "README.md's 'RustFFT + threadpool' row (CafRustFFTThreadpool, mod.rs:391-461: one pool task "
+                                    "per row, 3 FFTs per row): flavours.threads_%d.3fft_per_row" % threads,
+                           "single_thread_ms_per_surface": "README.md's single-thread 'RustFFT' row (CafRustFFT, mod.rs:121-166): "
+                                                           "flavours.threads_1.3fft_per_row",
+                           "all_usable_cores": "what mod.rs:405's ThreadPool::new(num_cpus::get()) would use on this host; slower than "
+                                               "16 threads here because 400 short row tasks do not amortise that many thread starts"},
     }
 
 

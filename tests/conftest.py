@@ -16,6 +16,46 @@ DATA = GOLDEN / "data"
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     _install_abort_trace()
+    _route_torch_copies_through_pinned_memory()
+
+
+def _route_torch_copies_through_pinned_memory():
+    """Test hygiene after the round-4 soak (profiles/r04_soak/run_24_abort.log): the one abort in 31
+    uncaptured full-suite runs was a GPU memory-access fault reported by the HSA runtime -- "Write access to a read-only page"
+    at a HOST heap address -- inside torch's `Tensor.cpu()`, i.e. in the runtime's pin-on-the-fly path for a device-to-host
+    copy into fresh PAGEABLE memory, with the device idle (a device-wide synchronize had returned and 100 ms of CPU work lay
+    in between).  None of this library's kernels or copies was running.  The tests' own result traffic therefore goes through
+    PINNED host memory (a plain DMA, no pinning of pageable ranges behind the process's back): `Tensor.cpu()` of a CUDA tensor
+    and `Tensor.cuda()` of a CPU tensor of 64 KiB or more are routed through `pin_memory`.  CAF_TESTS_PAGEABLE_COPIES=1
+    restores torch's default path (the library's own pageable-destination path, caf_surface_* into ordinary memory, is
+    exercised either way: it does not go through torch)."""
+    import os
+    if os.environ.get("CAF_TESTS_PAGEABLE_COPIES") == "1":
+        return
+    try:
+        import torch
+    except ImportError:
+        return
+    if getattr(torch.Tensor, "_caf_pinned_copies", False):
+        return
+    orig_cpu, orig_cuda = torch.Tensor.cpu, torch.Tensor.cuda
+    LIMIT = 1 << 16
+
+    def cpu(self, *args, **kwargs):
+        if self.is_cuda and not args and not kwargs and self.numel() * self.element_size() >= LIMIT:
+            host = torch.empty(self.shape, dtype=self.dtype, pin_memory=True)
+            host.copy_(self)
+            return host
+        return orig_cpu(self, *args, **kwargs)
+
+    def cuda(self, *args, **kwargs):
+        if (not self.is_cuda) and self.numel() * self.element_size() >= LIMIT and not self.is_pinned() and torch.cuda.is_available():
+            return orig_cuda(self.pin_memory(), *args, **kwargs)
+        return orig_cuda(self, *args, **kwargs)
+
+    torch.Tensor.cpu = cpu
+    torch.Tensor.cuda = cuda
+    torch.Tensor._caf_pinned_copies = True
 
 
 def _install_abort_trace():
