@@ -95,6 +95,9 @@ def parse_args(argv=None):
                     help="--in-process: comma-separated device ids instead of 0..N-1 (ids may repeat, e.g. 0,0 on a one-GPU box)")
     ap.add_argument("--blocks", type=int, default=10, help="further timed blocks of --steps launches after the reported one "
                     "(extra.headline_blocks: median / min / max of the step time)")
+    ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="G",
+                    help="ONE GPU, no collective: launch exactly what rank 0 of a G-GPU run launches per step (batch*G surfaces x "
+                         "rows [0, F/G)); for profiling the per-rank launch shapes (profiles/r04_rankshape_*), never a scaling figure")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no GPU work: launch + rendezvous + peak reduction + JSON relay on fabricated shard peaks "
                          "(gloo); what the CPU test suite runs")
@@ -942,9 +945,12 @@ def main():
     F = args.nfreq
     n_samp = args.n
     freqs = caf.bench_shifts() if F == 400 else np.linspace(-100.0, 100.0, F, endpoint=False)
-    lo, hi = caf.shard_range(F, rank, world)
+    emul = args.emulate_rank_of if (args.emulate_rank_of > 1 and world == 1) else 0
+    lo, hi = caf.shard_range(F, 0, emul) if emul else caf.shard_range(F, rank, world)
     rows = hi - lo
-    nsurf = args.batch * world  # surfaces per step (whole job)
+    nsurf = args.batch * (emul or world)  # surfaces per step (whole job)
+    if emul:
+        args.no_check = args.no_extra = True   # (the planted peaks need not lie in shard 0; the extras are N = 1 measurements)
     case = Case(eng, torch, dev, n_samp, freqs, args.dtype, nsurf, lo, hi)
     plan = case.plan
 
@@ -1064,6 +1070,9 @@ def main():
                             devname=devname, cu=cu, ndev=ndev,
                             peak_exchange=(f"{args.peak_reduce}, {'overlapped on a side stream' if overlap else 'on the main stream'}"
                                            if coll else None))
+        if emul:
+            res["config"]["parallelism"] = (f"EMULATED rank 0 of {emul}: one GPU launching that rank's per-step shape "
+                                            f"({nsurf} surfaces x rows [0, {rows})), no collective, not a scaling figure")
         res["extra"]["headline_blocks"] = block_stats(blocks_ms)
         res["extra"]["headline_blocks"]["how"] = (f"{len(blocks_ms)} further blocks of {K} steps after the reported one, each between "
                                                   "barriers (max over ranks); `value` comes from the reported block only")

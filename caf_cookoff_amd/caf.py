@@ -56,7 +56,7 @@ class Engine:
     def __init__(self, device: int = 0, lib=None):
         self._h = None
         self._plans = weakref.WeakSet()
-        self._host_bufs = weakref.WeakSet()   # live host_empty() buffers: close() refuses while any of them is alive
+        self._host_bufs = weakref.WeakValueDictionary()   # address -> live host_empty() buffer: close() refuses while any of them is alive
         self.lib = _lib.load(lib)
         h = ctypes.c_void_p()
         self._check(self.lib.caf_ctx_create(int(device), ctypes.byref(h)))
@@ -117,7 +117,7 @@ class Engine:
         self._check(self.lib.caf_host_alloc(self._h, max(nbytes, 1), ctypes.byref(p)))
         buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
         buf._caf_owner = self  # the buffer keeps the Engine alive: its context owns (and would free) this memory
-        self._host_bufs.add(buf)
+        self._host_bufs[p.value] = buf
         lib, h, addr = self.lib, self._h, p.value
 
         def _free():   # (h stays valid: the Engine cannot be closed or collected while the buffer lives)
