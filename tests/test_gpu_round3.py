@@ -29,6 +29,18 @@ def eng():
     e.close()
 
 
+def _mmap_array(shape, dtype, fill=0.0):
+    """A caller-owned buffer for caf_host_register that is its own anonymous mapping: page-aligned, and returned to the
+    kernel (munmap, which tears down every GPU mapping of the range) when the array dies -- not a heap block that goes back
+    to malloc and is handed out again, still mapped, as somebody else's copy destination."""
+    import mmap
+    count = int(np.prod(shape))
+    m = mmap.mmap(-1, max(count * np.dtype(dtype).itemsize, 1))
+    a = np.frombuffer(m, dtype=dtype, count=count).reshape(shape)
+    a[...] = fill
+    return a
+
+
 def _planted(rng, n, fs, f, lag, cdt=np.complex128):
     x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.hanning(n) if n >= 8 else \
         (rng.standard_normal(n) + 1j * rng.standard_normal(n))
@@ -95,7 +107,7 @@ def test_host_surface_in_place_equals_copied(dtype, n, eng, oracle):
     eng.surface_arrays(x, y, fr, FS, dtype=dtype, out=mid)
     assert np.array_equal(mid, ref) and (arena[:F] == -1.0).all() and (arena[2 * F:] == -1.0).all()
     # caller-owned memory, registered once
-    own = np.full((F + 2, L), -1.0, dtype=rdt)
+    own = _mmap_array((F + 2, L), rdt, -1.0)
     eng.host_register(own[1:F + 1])
     eng.surface_arrays(x, y, fr, FS, dtype=dtype, out=own[1:F + 1])
     assert np.array_equal(own[1:F + 1], ref) and (own[0] == -1.0).all() and (own[F + 1] == -1.0).all()
@@ -114,7 +126,7 @@ def test_host_memory_api_errors(eng):
     p = ctypes.c_void_p()
     assert lib.caf_host_alloc(eng._h, 0, ctypes.byref(p)) == _lib.CAF_ERR_BAD_ARG
     assert lib.caf_host_alloc(None, 64, ctypes.byref(p)) == _lib.CAF_ERR_BAD_ARG
-    buf = np.zeros(4096, dtype=np.float64)
+    buf = _mmap_array((4096,), np.float64)
     assert lib.caf_host_unregister(eng._h, ctypes.c_void_p(buf.ctypes.data)) == _lib.CAF_ERR_BAD_ARG
     assert b"caf_host_register" in lib.caf_last_error_string()
     eng.host_register(buf)
@@ -560,7 +572,7 @@ def test_views_in_place_on_pinned_memory(eng):
         psrc = eng.host_empty(surf.shape, np.float64)
         psrc[:] = surf
         assert np.array_equal(eng.surface_view(psrc, view), ref)
-        big = np.zeros((14, 256))
+        big = _mmap_array((14, 256), np.float64)
         big[1:13] = surf
         eng.host_register(big[:6])                      # the first six rows only: big[1:13] straddles the edge
         assert np.array_equal(eng.surface_view(big[1:13], view), ref)
