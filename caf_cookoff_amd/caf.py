@@ -531,7 +531,7 @@ class MultiSurface:
         self.n, self.rows, self.ndev, self.dtype = int(n), len(self.freqs), len(devices), dtype
         self._cdt = np.complex128 if dtype == "c128" else np.complex64
         self._rdt = np.float64 if dtype == "c128" else np.float32
-        self._host = []  # arrays over caf_multi_surface_host_alloc memory (freed with the object)
+        self._host_bufs = weakref.WeakValueDictionary()  # address -> live host_empty() buffer (close() refuses under them)
 
     def worker_info(self, worker: int):
         """-> (device, row_begin, row_end, row-kernel name)."""
@@ -546,13 +546,17 @@ class MultiSurface:
         return int(self.lib.caf_multi_surface_slab(self._h, int(worker)) or 0)
 
     def host_empty(self, shape, dtype) -> np.ndarray:
-        """``caf_multi_surface_host_alloc``: pinned memory EVERY worker writes in place.  Lives until :meth:`close`."""
+        """``caf_multi_surface_host_alloc``: pinned memory EVERY worker writes in place.  The array keeps this object
+        alive; the memory is released when the array (and every view of it) is gone, and :meth:`close` refuses before."""
         dt = np.dtype(dtype)
         nbytes = max(int(np.prod(shape)) * dt.itemsize, 1)
         p = ctypes.c_void_p()
         check(self.lib.caf_multi_surface_host_alloc(self._h, nbytes, ctypes.byref(p)), self.lib)
         buf = (ctypes.c_char * nbytes).from_address(p.value)
         buf._caf_owner = self  # the array keeps this object (and so the memory) alive
+        self._host_bufs[p.value] = buf
+        lib, h, addr = self.lib, self._h, p.value
+        weakref.finalize(buf, lambda: lib.caf_multi_surface_host_free(h, ctypes.c_void_p(addr)))
         return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
     def run(self, needle, haystack, want_surface: bool = True, out: Optional[np.ndarray] = None):
@@ -591,6 +595,9 @@ class MultiSurface:
 
     def close(self):
         if getattr(self, "_h", None):
+            if len(self._host_bufs):
+                raise RuntimeError(f"MultiSurface.close(): {len(self._host_bufs)} host_empty() array(s) still alive; delete them "
+                                   "(and every view of them) first: the object owns the pinned memory under them")
             self.lib.caf_multi_surface_destroy(self._h)
         self._h = None
 

@@ -314,7 +314,8 @@ int caf_multi_stream_destroy(caf_multi_stream *ms);
  *                              (caf_rccl_library names the file; default "librccl.so.1"): the library does not link it.
  * surface: nfreq x 2n of the dtype's real type or NULL; row_idx / row_val: nfreq entries or NULL; needle / haystack: n
  * complex of the dtype (host pointers).  Blocks until every result is in host memory.  If workers fail, the call returns
- * the status of the first failing one (by position) with its message. */
+ * the status of the first failing one (by position) with its message.  Like a context, the object is NOT thread-safe: one
+ * caf_multi_surface_run at a time (the object's own worker threads are an implementation detail of that one call). */
 typedef struct caf_multi_surface caf_multi_surface;
 enum caf_multi_flags {
     CAF_MULTI_REDUCE_RCCL = 1,

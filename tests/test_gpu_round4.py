@@ -72,6 +72,9 @@ def test_multi_surface_kats_bit_equal_to_unsharded(kat, workers, eng, oracle):
     # peaks only
     _, ridx, rval, pk = ms.run(nd, hs, want_surface=False)
     assert np.array_equal(ridx, ridx0) and (pk["freq"], int(pk["idx"])) == tuple(exp)
+    with pytest.raises(RuntimeError, match="still alive"):   # the object owns the pinned arena under `pinned`
+        ms.close()
+    del pinned, surf, out
     ms.close()
 
 
