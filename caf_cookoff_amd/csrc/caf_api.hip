@@ -113,9 +113,12 @@ static hipError_t guarded_alloc(void **p, size_t bytes, bool pinned, const char 
     r.base = base; r.bytes = bytes; r.guard = g; r.pinned = pinned; r.line = line;
     r.file = strrchr(file, '/') ? strrchr(file, '/') + 1 : file;
     (void)hipGetDevice(&r.device);
-    {
+    try {
         std::lock_guard<std::mutex> lk(g_guard_mu);
         g_guarded[base + g] = r;
+    } catch (...) {  // (the registry could not grow: give the memory back rather than hand out an unchecked block)
+        (void)(pinned ? hipHostFree(base) : hipFree(base));
+        return hipErrorOutOfMemory;
     }
     g_guard_live.fetch_add(1);
     *p = base + g;
