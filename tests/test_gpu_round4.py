@@ -567,6 +567,7 @@ def test_wave_row_kernel_variant_vs_oracle(oracle, monkeypatch):
     if not caf.MEASURE_LIB_PATH.exists():
         pytest.skip("measurement library not built")
     monkeypatch.setenv("CAF_ROW_KERNEL", "4")
+    caf.debug_guard_bands(4096, lib=caf.MEASURE_LIB_PATH)   # (the measurement library has its own allocation registry)
     eng = caf.Engine(0, lib=caf.MEASURE_LIB_PATH)
     try:
         fr = caf.bench_shifts()
@@ -594,8 +595,11 @@ def test_wave_row_kernel_variant_vs_oracle(oracle, monkeypatch):
         p128 = eng.plan(4096, fr, FS, dtype="c128")
         assert "k_seq_rows<double" in p128.kernel_name
         p128.close()
+        checked, bad = caf.debug_check_guards(lib=caf.MEASURE_LIB_PATH)   # tables, phasors, spectra, ticket word: fences intact
+        assert bad == 0 and checked >= 4
     finally:
         eng.close()
+        caf.debug_guard_bands(0, lib=caf.MEASURE_LIB_PATH)
 
 
 def test_engine_close_refuses_under_live_host_memory():
