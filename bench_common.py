@@ -1,0 +1,277 @@
+"""bench_common.py -- what bench.py and bench_extras.py share: the constants of the contract, the algorithmic-byte count of
+SURVEY.md section 8(d), the roofline / traffic objects, the one-line output discipline, the device-resident workload (`Case`)
+and the phase watchdog that keeps a run from hanging silently."""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+FS = 48000
+N_SAMP = 4096
+EXTRAS_LIMIT_S = 240           # N > 1 only: see main()
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy
+
+
+# ------------------------------------------------------------------------------ the line --
+# Rank 0 prints ONE JSON line on stdout -- and nothing else may reach stdout: libraries under this process (RCCL prints a
+# version banner on fd 1 at communicator creation, the HIP runtime prints diagnostics) write to the process's fd 1
+# directly.  So the real stdout is put aside at start-up, fd 1 is pointed at stderr for everything that runs in between,
+# and emit_line() writes the one line to the saved descriptor.
+_REAL_STDOUT = None
+
+
+def guard_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, data)
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
+# ------------------------------------------------------------------------------ helpers --
+def algorithmic_bytes(n_surfaces: int, rows_local: int, n: int, dtype: str) -> int:
+    """inputs once + outputs once.  Per surface and row shard:
+    needle+haystack 2*n*csize, surface rows*2n*rsize, row peaks rows*(8+rsize);
+    freq list rows*8 once per launch."""
+    csize, rsize = (16, 8) if dtype == "c128" else (8, 4)
+    per_surface = 2 * n * csize + rows_local * (2 * n * rsize + 8 + rsize)
+    return n_surfaces * per_surface + rows_local * 8
+
+
+_KERNEL_HEADERS = {  # the headers a row kernel's code comes from (everything else in csrc/ cannot change it)
+    "k_seq_rows": ("cplx.hpp", "kernels_fused4096.hpp", "kernels_seq4096.hpp"),
+    "k_duo_rows": ("cplx.hpp", "kernels_fused4096.hpp", "kernels_seq4096.hpp", "kernels_duo4096.hpp"),
+    "k_chain_rows": ("cplx.hpp", "kernels_fused4096.hpp", "kernels_seq4096.hpp", "kernels_chain.hpp"),
+}
+
+
+def kernel_source_hash(kernel_name: str = "") -> str:
+    """sha256 over the sources of one kernel (the csrc/*.hpp it is written in; every __global__ function
+    lives in a header, caf_api.hip is host code; unknown kernels: all headers): ties a
+    profiles/*/traffic.json to the code it measured."""
+    files = None
+    for key, names in _KERNEL_HEADERS.items():
+        if key in kernel_name:
+            files = [ROOT / "caf_cookoff_amd" / "csrc" / n for n in names]
+    if files is None:
+        files = sorted((ROOT / "caf_cookoff_amd" / "csrc").glob("*.hpp"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(kernel_name: str, nsurf: int, dtype: str, abytes=None):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes; tools/profile_pack.py).  Collected offline, so it is only
+    reported when the profile's kernel-source hash equals the running code's; otherwise null."""
+    here = kernel_source_hash(kernel_name)
+    best, stale = None, None
+    for f in sorted((ROOT / "profiles").glob("*/traffic.json")):
+        try:
+            t = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if t.get("kernel") and t["kernel"] in kernel_name and t.get("surfaces_per_launch") == nsurf and \
+                t.get("dtype") == ("f64" if dtype == "c128" else "f32") and \
+                (abytes is None or t.get("algorithmic_bytes_per_launch") in (None, abytes)):  # same rows per launch too
+            if t.get("source_hash") == here:
+                best = (t["traffic_bytes_per_launch"], str(f.relative_to(ROOT)))
+            else:
+                stale = str(f.relative_to(ROOT))
+    return best, stale
+
+
+def host_cpu_info():
+    model = "unknown"
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"model": model, "nproc_online": os.cpu_count() or 1, "nproc_usable": usable}
+
+
+class Case:
+    """One (n, freq list, dtype, row shard, batch) workload with its device buffers."""
+
+    def __init__(self, eng, torch, dev, n, freqs, dtype, batch, lo, hi, seed0=1000, want_surface=True):
+        import numpy as np
+        from caf_cookoff_amd.synth import make_batch
+        self.torch, self.n, self.dtype, self.batch, self.freqs = torch, n, dtype, batch, freqs
+        self.rows = hi - lo
+        cdt = np.complex128 if dtype == "c128" else np.complex64
+        rdt = torch.float64 if dtype == "c128" else torch.float32
+        nd_h, hs_h, self.lags, self.fos = make_batch(batch, n, FS, seed0=seed0, dtype=cdt)
+        self.nd = torch.from_numpy(nd_h).to(dev)
+        self.hs = torch.from_numpy(hs_h).to(dev)
+        self.plan = eng.plan(n, freqs, FS, dtype=dtype, row_begin=lo, row_end=hi)
+        self.surf = torch.empty((batch, self.rows, 2 * n), dtype=rdt, device=dev) if want_surface else None
+        self.ridx = torch.empty((batch, self.rows), dtype=torch.int64, device=dev)
+        self.rval = torch.empty((batch, self.rows), dtype=rdt, device=dev)
+        self.peak = torch.empty((batch, 4), dtype=torch.float64, device=dev)  # caf_peak records (32 B)
+        self.peak_i = self.peak.view(torch.int64)
+
+    def launch(self, plan=None, peak=None):
+        (plan or self.plan).surface_dev(self.nd.data_ptr(), self.hs.data_ptr(), self.batch,
+                                        self.surf.data_ptr() if self.surf is not None else None,
+                                        self.ridx.data_ptr(), self.rval.data_ptr(),
+                                        (self.peak if peak is None else peak).data_ptr())
+
+    def host_peaks(self):
+        import numpy as np
+        pk = self.peak.cpu().numpy().view([("val", "<f8"), ("freq", "<f8"), ("idx", "<u8"), ("row", "<i8")])[:, 0]
+        return pk["idx"].astype(np.int64), pk["freq"], pk["row"]
+
+    def check(self, g_idx, g_freq, tol_hz):
+        import numpy as np
+        for b in range(self.batch):
+            want_f = self.freqs[np.argmin(np.abs(self.freqs - self.fos[b]))]
+            assert int(g_idx[b]) == self.lags[b], f"surface {b}: tau {g_idx[b]} != {self.lags[b]}"
+            assert abs(float(g_freq[b]) - want_f) <= tol_hz + 1e-9, f"surface {b}: f {g_freq[b]} vs {self.fos[b]}"
+
+    def timed(self, steps, warmup):
+        """-> (seconds per step, kernel ms per launch, launches)."""
+        torch = self.torch
+        for _ in range(warmup):
+            self.launch()
+        torch.cuda.synchronize()
+        self.plan.timing_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.launch()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ms, launches = self.plan.timing_end()
+        return el / steps, ms / max(1, launches), launches
+
+    def close(self):
+        self.plan.close()
+        self.surf = self.ridx = self.rval = self.peak = self.peak_i = self.nd = self.hs = None
+
+
+def block_stats(ms_list):
+    import statistics
+    return {"blocks": len(ms_list), "ms_per_step_median": statistics.median(ms_list) if ms_list else None,
+            "ms_per_step_min": min(ms_list) if ms_list else None, "ms_per_step_max": max(ms_list) if ms_list else None}
+
+
+def roofline_entry(abytes, kern_ms):
+    achieved = abytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+
+
+def secondary_entry(bound, ceil_ms, kern_ms, abytes, how):
+    return {"bound": bound, "ceiling_ms": ceil_ms, "frac_of_ceiling": ceil_ms / kern_ms,
+            "ceiling_frac_of_hbm": abytes / (ceil_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "how": how}
+
+
+def traffic_fields(kernel_name, nsurf, dtype, abytes):
+    """`traffic` (HBM bytes per launch from the committed PMC passes, only if their kernel-source hash equals
+    the running code's), where it came from, and its ratio to the algorithmic bytes."""
+    traffic, stale = profiled_traffic(kernel_name, nsurf, dtype, abytes)
+    return {"traffic": traffic[0] if traffic else None,
+            "traffic_over_algorithmic": traffic[0] / abytes if traffic else None,
+            "traffic_source": (traffic[1] + " (rocprofv3 PMC passes of this command, collected offline; "
+                               "kernel-source hash matches)") if traffic else
+                              (f"none: {stale} was measured on other kernel sources" if stale else None)}
+
+
+# --------------------------------------------------------------------------- phase watchdog --
+class PhaseWatchdog:
+    """A run that hangs must end by itself, loudly, and must never print a line it did not measure (the join that cannot be
+    skipped, mod.rs:452-457, has no timeout in the reference; a collective over 8 GPUs needs one).  One daemon thread per
+    process watches the phase the main thread says it is in -- rendezvous, set-up, warm-up, the correctness gate, the timed
+    region, the further blocks, the extras, the CPU comparator -- each with its own limit.  When a phase overruns, the process
+    writes ONE stderr line naming its rank, its device and the phase and leaves with status 3 through os._exit (a thread
+    blocked inside a collective cannot be unwound; the process ends, it is never restarted or replaced).  `on_expiry` (per
+    phase) runs first, under `line_lock`: the extras phases use it to print the headline that was measured BEFORE the hang.
+    Limits (seconds) can be overridden for tests: CAF_BENCH_PHASE_LIMITS="timed=5,warmup=5"."""
+
+    LIMITS = {"rendezvous": 150.0, "setup": 300.0, "warmup": 120.0, "check": 120.0, "timed": 180.0, "blocks": 300.0,
+              "ceiling": 180.0, "extras": 900.0, "multi_extras": float(EXTRAS_LIMIT_S), "cpu_baseline": 180.0, "finish": 120.0}
+
+    def __init__(self, rank: int, device):
+        self.rank, self.device = rank, device
+        self.limits = dict(self.LIMITS)
+        for item in filter(None, os.environ.get("CAF_BENCH_PHASE_LIMITS", "").split(",")):
+            k, _, v = item.partition("=")
+            self.limits[k.strip()] = float(v)
+        self.line_lock = threading.Lock()
+        self.printed = False       # the one JSON line has been written (by whoever holds line_lock)
+        self._lock = threading.Lock()
+        self._phase, self._deadline, self._limit, self._cb = None, None, None, None
+        self.history = []          # (phase, seconds) of every finished phase: goes into extra.phase_seconds
+        self._t_enter = None
+        threading.Thread(target=self._watch, name="bench-watchdog", daemon=True).start()
+
+    def enter(self, phase: str, on_expiry=None):
+        now = time.monotonic()
+        with self._lock:
+            if self._phase is not None:
+                self.history.append((self._phase, now - self._t_enter))
+            self._limit = self.limits.get(phase, 300.0)
+            self._phase, self._deadline, self._cb, self._t_enter = phase, now + self._limit, on_expiry, now
+
+    def leave(self):
+        now = time.monotonic()
+        with self._lock:
+            if self._phase is not None:
+                self.history.append((self._phase, now - self._t_enter))
+            self._phase, self._deadline, self._cb = None, None, None
+
+    def phase_seconds(self):
+        out = {}
+        for ph, s in self.history:
+            out[ph] = round(out.get(ph, 0.0) + s, 3)
+        return out
+
+    def _watch(self):
+        while True:
+            time.sleep(0.2)
+            with self._lock:
+                ph, dl, lim, cb = self._phase, self._deadline, self._limit, self._cb
+            if ph is None or time.monotonic() <= dl:
+                continue
+            try:
+                if cb is not None:
+                    with self.line_lock:
+                        cb()
+            finally:
+                os.write(2, (f"bench.py: rank {self.rank} (device {self.device}) did not finish phase '{ph}' within {lim:g} s; "
+                             "leaving with status 3" + ("" if self.printed else " and without a result line") + "\n").encode())
+                os._exit(3)
+
+
+def under_rocprofiler() -> bool:
+    """rocprofv3 preloads its tool library into the profiled program, and that library initialises the GPU before the program's
+    first line runs: from such a process no other GPU program may be started (tools/profile_run.sh, bench.self_launch)."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ)

@@ -113,6 +113,9 @@ SYMBOLS = [
     ("caf_multi_surface_worker_info", _int, [_vp, _int, ctypes.POINTER(_int), ctypes.POINTER(_sz), ctypes.POINTER(_sz),
                                              ctypes.POINTER(ctypes.c_char_p)]),
     ("caf_multi_surface_run", _int, [_vp, _vp, _vp, _vp, _up, _vp, _pp]),
+    ("caf_multi_surface_run_batch", _int, [_vp, _vp, _vp, _sz, _up, _vp, _pp]),
+    ("caf_multi_surface_batch_results", _int, [_vp, _int, ctypes.POINTER(_sz), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                               ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     ("caf_multi_surface_run_stats", _int, [_vp, _dp, _pp]),
     ("caf_multi_surface_timing_begin", _int, [_vp]),
     ("caf_multi_surface_timing_end", _int, [_vp, _dp, _up]),

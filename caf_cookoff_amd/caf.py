@@ -57,6 +57,7 @@ class Engine:
         self._h = None
         self._plans = weakref.WeakSet()
         self._host_bufs = weakref.WeakValueDictionary()   # address -> live host_empty() buffer: close() refuses while any of them is alive
+        self._registered = {}                             # address -> array registered with host_register (kept alive until unregistered)
         self.lib = _lib.load(lib)
         h = ctypes.c_void_p()
         self._check(self.lib.caf_ctx_create(int(device), ctypes.byref(h)))
@@ -78,8 +79,9 @@ class Engine:
                                    "view of them) before closing the engine that owns their memory")
             for p in list(self._plans):
                 p.close()
-            self._check(self.lib.caf_ctx_destroy(self._h))
+            self._check(self.lib.caf_ctx_destroy(self._h))   # (unregisters what is still registered, before the arrays go)
             self._h = None
+            self._registered.clear()
 
     def __del__(self):  # best effort
         try:
@@ -128,11 +130,15 @@ class Engine:
     def host_register(self, arr: np.ndarray):
         """``caf_host_register``: page-lock a caller-owned array (~1.2 ms per 26 MB: once per buffer,
         not per call) so that surfaces can be written into it in place; undo with
-        :meth:`host_unregister` before the array is freed."""
+        :meth:`host_unregister`.  Whole pages only (page-aligned address, size a multiple of the page size: an
+        ``mmap`` buffer, not a heap block); the Engine keeps a reference to the array while it is registered."""
         self._check(self.lib.caf_host_register(self._h, ctypes.c_void_p(arr.ctypes.data), arr.nbytes))
+        # the registered range must outlive its registration: the Engine holds the array until host_unregister (or close)
+        self._registered[arr.ctypes.data] = arr
 
     def host_unregister(self, arr: np.ndarray):
         self._check(self.lib.caf_host_unregister(self._h, ctypes.c_void_p(arr.ctypes.data)))
+        self._registered.pop(arr.ctypes.data, None)
 
     # -- a1 -----------------------------------------------------------------------
     def apply_freq_shift(self, samples, freq_shift: float, fs: int) -> np.ndarray:
@@ -529,6 +535,7 @@ class MultiSurface:
                                                 ctypes.byref(h)), self.lib)
         self._h = h
         self.n, self.rows, self.ndev, self.dtype = int(n), len(self.freqs), len(devices), dtype
+        self.surface_on_device = bool(surface_on_device)
         self._cdt = np.complex128 if dtype == "c128" else np.complex64
         self._rdt = np.float64 if dtype == "c128" else np.float32
         self._host_bufs = weakref.WeakValueDictionary()  # address -> live host_empty() buffer (close() refuses under them)
@@ -559,8 +566,15 @@ class MultiSurface:
         weakref.finalize(buf, lambda: lib.caf_multi_surface_host_free(h, ctypes.c_void_p(addr)))
         return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
-    def run(self, needle, haystack, want_surface: bool = True, out: Optional[np.ndarray] = None):
-        """One surface -> (surface[F,2n] | None, row_idx[F], row_val[F], peak record)."""
+    def run(self, needle, haystack, want_surface: Optional[bool] = None, out: Optional[np.ndarray] = None):
+        """One surface -> (surface[F,2n] | None, row_idx[F], row_val[F], peak record).  ``want_surface`` defaults to True, and
+        to False for an object created with ``surface_on_device=True`` (its rows stay in the workers' HBM: :meth:`slab_ptr`);
+        asking such an object for a host surface raises ValueError."""
+        if want_surface is None:
+            want_surface = not self.surface_on_device
+        if want_surface and self.surface_on_device:
+            raise ValueError("this MultiSurface keeps the surface on the devices (surface_on_device=True): "
+                             "call run(..., want_surface=False) and read slab_ptr(worker)")
         nd = np.ascontiguousarray(needle, dtype=self._cdt)
         hs = np.ascontiguousarray(haystack, dtype=self._cdt)
         if nd.shape != (self.n,) or hs.shape != (self.n,):
@@ -575,6 +589,44 @@ class MultiSurface:
                                              ctypes.c_void_p(rval.ctypes.data), peak.ctypes.data_as(ctypes.POINTER(CafPeak))),
               self.lib)
         return surf, ridx, rval, peak[0]
+
+    def run_batch(self, needles=None, haystacks=None, batch: Optional[int] = None, want_rows: bool = True):
+        """``caf_multi_surface_run_batch``: B pairs in one call -> (row_idx[B,F] | None, row_val[B,F] | None, peaks[B]).
+        needles / haystacks: [B][n] complex arrays; both None re-runs the ``batch`` pairs of the previous call, which are
+        still in every worker's HBM.  Surfaces stay on the devices (``surface_on_device=True``: :meth:`batch_results`)."""
+        if (needles is None) != (haystacks is None):
+            raise ValueError("needles and haystacks must both be given or both be None")
+        if needles is not None:
+            nd = np.ascontiguousarray(needles, dtype=self._cdt)
+            hs = np.ascontiguousarray(haystacks, dtype=self._cdt)
+            if nd.ndim != 2 or nd.shape != hs.shape or nd.shape[1] != self.n:
+                raise AssertionError("assertion failed: a.len() == self.n")  # xcor_rustfft.rs:54-55
+            B = nd.shape[0]
+            pn, ph = ctypes.c_void_p(nd.ctypes.data), ctypes.c_void_p(hs.ctypes.data)
+        else:
+            if batch is None:
+                raise ValueError("batch= is needed to re-run the resident pairs")
+            B, pn, ph = int(batch), None, None
+        ridx = np.zeros((B, self.rows), dtype=np.uint64) if want_rows else None
+        rval = np.zeros((B, self.rows), dtype=self._rdt) if want_rows else None
+        peaks = np.zeros(B, dtype=self.PEAK_DTYPE)
+        check(self.lib.caf_multi_surface_run_batch(self._h, pn, ph, B, _uptr(ridx) if want_rows else None,
+                                                   ctypes.c_void_p(rval.ctypes.data) if want_rows else None,
+                                                   peaks.ctypes.data_as(ctypes.POINTER(CafPeak))), self.lib)
+        return ridx, rval, peaks
+
+    def batch_results(self, worker: int):
+        """``caf_multi_surface_batch_results`` -> dict(batch, slab, row_idx, row_val, peaks: DEVICE addresses on the worker's
+        GPU (0 if absent); shard_peaks: the worker's find_peak records of the last batch as a structured array)."""
+        b = ctypes.c_size_t()
+        sl, ri, rv, pk, hp = (ctypes.c_void_p() for _ in range(5))
+        check(self.lib.caf_multi_surface_batch_results(self._h, int(worker), ctypes.byref(b), ctypes.byref(sl), ctypes.byref(ri),
+                                                       ctypes.byref(rv), ctypes.byref(pk), ctypes.byref(hp)), self.lib)
+        shard = np.zeros(0, dtype=self.PEAK_DTYPE)
+        if hp.value and b.value:
+            shard = np.frombuffer((ctypes.c_char * (b.value * 32)).from_address(hp.value), dtype=self.PEAK_DTYPE).copy()
+        return {"batch": b.value, "slab": sl.value or 0, "row_idx": ri.value or 0, "row_val": rv.value or 0,
+                "peaks": pk.value or 0, "shard_peaks": shard}
 
     def run_stats(self):
         """Last run: ({'shards_s', 'reduce_s'}, shard peak records[ndev])."""

@@ -12,19 +12,23 @@
 
 namespace caf {
 
-// red[0] = this shard's contribution to the max (0.0 if the shard has no peak: the reference's initial maximum)
-__global__ void k_shard_peak_val(const caf_peak *__restrict__ peak, double *__restrict__ red)
+// One reduction covers `count` surfaces (1 for caf_multi_surface_run, B for caf_multi_surface_run_batch).  The device buffer
+// `red` is four arrays of `count` 8-byte words: [val | gmax | key | gkey].
+// val[b] = this shard's contribution to the max of surface b (0.0 if the shard has no peak: the reference's initial maximum)
+__global__ void k_shard_peak_val(const caf_peak *__restrict__ peak, double *__restrict__ red, int count)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) red[0] = peak->row >= 0 ? peak->val : 0.0;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < count) red[b] = peak[b].row >= 0 ? peak[b].val : 0.0;
 }
 
-// red[1] = gmax (all-reduced); key[0] = this shard's candidate for the min-key reduction
-__global__ void k_shard_peak_key(const caf_peak *__restrict__ peak, const double *__restrict__ red, uint64_t *__restrict__ key)
+// gmax[b] = red[count + b] (all-reduced); key[b] = this shard's candidate for the min-key reduction of surface b
+__global__ void k_shard_peak_key(const caf_peak *__restrict__ peak, double *__restrict__ red, int count)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const double gmax = red[1];
-        const bool mine = peak->row >= 0 && gmax > 0.0 && peak->val == gmax;
-        key[0] = mine ? (((uint64_t)peak->row << 32) | (peak->idx & 0xffffffffull)) : ~0ull;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < count) {
+        const double gmax = red[count + b];
+        const bool mine = peak[b].row >= 0 && gmax > 0.0 && peak[b].val == gmax;
+        ((uint64_t *)red)[2 * (size_t)count + b] = mine ? (((uint64_t)peak[b].row << 32) | (peak[b].idx & 0xffffffffull)) : ~0ull;
     }
 }
 

@@ -20,6 +20,11 @@
  *   - a context is bound to one GPU and is NOT thread-safe; use one per thread.
  *   - lengths: n must be a power of two >= 1 (xcor_rustfft.rs:2 "Assumes
  *     equal-length, power of 2"); caf_surface pads to 2n itself (mod.rs:130-131).
+ *     The reference's FFTplanner would take any length: INTEGRATION.md "Where the
+ *     ABI refuses what the reference accepts".
+ *   - fs == 0 is accepted and gives what the reference gives (mod.rs:54-56: dt = inf,
+ *     NaN phasors): an all-NaN surface, rows (idx 0, val 0.0), peak (0.0, 0), row -1;
+ *     apply_freq_shift leaves sample 0 and turns every later sample into NaN.
  *   - there is NO CPU fallback: without a usable HIP device every call fails
  *     with CAF_ERR_NO_DEVICE / CAF_ERR_HIP.
  */
@@ -33,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CAF_ABI_VERSION 3
+#define CAF_ABI_VERSION 4
 
 enum caf_status {
     CAF_OK = 0,
@@ -134,6 +139,11 @@ int caf_surface_c64(caf_ctx *ctx, const float *needle, const float *haystack,
  * (page-locking 26 MB costs ~1.2 ms the first time: do it once for a long-lived buffer, never per call) until
  * caf_host_unregister / caf_ctx_destroy.  A Rust host keeps one such arena inside its CafHip backend and builds
  * the Vec<CafSurfaceRow> rows (mod.rs:156-161) from it. */
+/* caf_host_register takes WHOLE PAGES only (CAF_ERR_BAD_ARG unless ptr and bytes are multiples of sysconf(_SC_PAGESIZE)):
+ * page-locking works on pages, so a range that starts or ends inside a page would pin, and map for the GPU, whatever else the
+ * allocator keeps in that page -- and leave it so after the block has gone back to the heap.  Register memory whose lifetime
+ * the caller controls (mmap, aligned_alloc of a page multiple, an arena kept for the life of the context) and unregister it
+ * BEFORE it is unmapped or freed.  Rows are callee-owned in the reference (mod.rs:156-161), which is why the arena exists. */
 int caf_host_alloc(caf_ctx *ctx, size_t bytes, void **out);
 int caf_host_free(caf_ctx *ctx, void *ptr);
 int caf_host_register(caf_ctx *ctx, void *ptr, size_t bytes);
@@ -336,6 +346,29 @@ int caf_multi_surface_worker_info(const caf_multi_surface *h, int worker, int *d
                                   const char **kernel_name);
 int caf_multi_surface_run(caf_multi_surface *h, const void *needle, const void *haystack, void *surface,
                           uint64_t *row_idx, void *row_val, caf_peak *peak);
+/* B surfaces per call -- the loop of benches/caf_bench.rs:150-168 (one caf_surface call per iteration, each fanning its rows out
+ * over the pool and joining them, mod.rs:391-461) handed to the operator as ONE call, so that every device runs ONE launch of
+ * its row kernel over its rows [row_begin, row_end) of ALL B surfaces instead of B launches with the chip idle in between.
+ *   needles, haystacks : [batch][n] complex of the dtype, host pointers; every worker takes its own copy of all B pairs (the
+ *                        inputs are replicated, the haystack spectra are computed on every device).  Both NULL: re-run the
+ *                        pairs of the previous call, which are still in every worker's HBM (batch must equal that call's) --
+ *                        the form bench.py times ("inputs already resident in HBM").
+ *   row_idx / row_val  : [batch][nfreq] or NULL (NULL: the row records stay on the devices, caf_multi_surface_batch_results)
+ *   peaks              : [batch] find_peak records (mod.rs:31-42; largest value, among equal values the lowest global row),
+ *                        joined on the host (flags == 0: caf_multi_surface_reduce per surface) or, with CAF_MULTI_REDUCE_RCCL,
+ *                        by ONE grouped ncclAllReduce(max) over the B shard values and ONE ncclAllReduce(min) over the B
+ *                        (global_row << 32 | idx) keys per call, on the workers' streams over xGMI.
+ * With CAF_MULTI_SURFACE_ON_DEVICE every worker keeps its slab [batch][row_end - row_begin][2n] of the B surfaces in its own
+ * HBM until the next batch call (the surface stays sharded); without that flag the batch call computes
+ * row records and peaks only (for host-resident surfaces call caf_multi_surface_run per pair).  No collective on the data path.
+ * caf_multi_surface_timing_* and caf_multi_surface_run_stats cover batch calls too.  Blocks until the results are in host memory. */
+int caf_multi_surface_run_batch(caf_multi_surface *h, const void *needles, const void *haystacks, size_t batch,
+                                uint64_t *row_idx, void *row_val, caf_peak *peaks);
+/* one worker's share of the last batch call: the number of pairs resident, DEVICE addresses (on that worker's GPU) of its slab
+ * [batch][rows][2n] (NULL without CAF_MULTI_SURFACE_ON_DEVICE), row records [batch][rows] and shard find_peak records [batch]
+ * (global row positions), and the pinned host copy of the latter; any pointer may be NULL */
+int caf_multi_surface_batch_results(caf_multi_surface *h, int worker, size_t *batch, void **d_slab, uint64_t **d_row_idx,
+                                    void **d_row_val, caf_peak **d_peaks, const caf_peak **h_peaks);
 /* last run: seconds2 = {fan-out + shards + join of the worker threads, peak reduction}; shard_peaks[ndev] = every
  * worker's own find_peak record (global row positions); either may be NULL */
 int caf_multi_surface_run_stats(caf_multi_surface *h, double *seconds2, caf_peak *shard_peaks);
@@ -344,7 +377,7 @@ int caf_multi_surface_run_stats(caf_multi_surface *h, double *seconds2, caf_peak
 int caf_multi_surface_timing_begin(caf_multi_surface *h);
 int caf_multi_surface_timing_end(caf_multi_surface *h, double *kernel_ms_total, uint64_t *launches);
 /* host memory EVERY worker may write in place (pinned, portable): the multi-device counterpart of caf_host_alloc /
- * caf_host_register; released by the matching call or by caf_multi_surface_destroy */
+ * caf_host_register (whole pages only, like it); released by the matching call or by caf_multi_surface_destroy */
 int caf_multi_surface_host_alloc(caf_multi_surface *h, size_t bytes, void **out);
 int caf_multi_surface_host_free(caf_multi_surface *h, void *ptr);
 int caf_multi_surface_host_register(caf_multi_surface *h, void *ptr, size_t bytes);

@@ -269,6 +269,33 @@ class CafHipMulti {
         return rows;
     }
 
+    // The loop of benches/caf_bench.rs:150-168 as ONE call (caf_multi_surface_run_batch): B pairs in, the B (freq, idx)
+    // answers of find_peak out; every device runs ONE launch over its row shard of all B surfaces.  `row_val` (optional)
+    // receives the [B][F] row peak values.
+    std::vector<std::pair<double, std::size_t>> find_peaks_batch(const std::vector<std::vector<Complex64>> &needles,
+                                                                 const std::vector<std::vector<Complex64>> &haystacks,
+                                                                 std::vector<double> *row_val = nullptr)
+    {
+        if (needles.size() != haystacks.size()) throw std::runtime_error("CafHipMulti::find_peaks_batch: needles vs haystacks");
+        const std::size_t B = needles.size(), F = freqs_.size();
+        std::vector<Complex64> a(B * n_), b(B * n_);
+        for (std::size_t k = 0; k < B; ++k) {
+            if (needles[k].size() != n_ || haystacks[k].size() != n_)  // Xcor::run's assert (xcor_rustfft.rs:54-55)
+                throw std::runtime_error("assertion failed: a.len() == self.n");
+            std::copy(needles[k].begin(), needles[k].end(), a.begin() + k * n_);
+            std::copy(haystacks[k].begin(), haystacks[k].end(), b.begin() + k * n_);
+        }
+        std::vector<caf_peak> pk(B);
+        std::vector<uint64_t> idx(row_val ? B * F : 0);
+        if (row_val) row_val->assign(B * F, 0.0);
+        check(caf_multi_surface_run_batch(h_, a.data(), b.data(), B, row_val ? idx.data() : nullptr, row_val ? row_val->data() : nullptr,
+                                          pk.data()),
+              "caf_multi_surface_run_batch");
+        std::vector<std::pair<double, std::size_t>> out;
+        for (const caf_peak &p : pk) out.emplace_back(p.freq, static_cast<std::size_t>(p.idx));
+        return out;
+    }
+
   private:
     std::size_t n_;
     std::vector<double> freqs_;

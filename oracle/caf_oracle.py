@@ -68,14 +68,21 @@ def load_pair(data_dir, needle_name: str, haystack_name: str):
 # --------------------------------------------------------------------------
 def np_phase_step(freq_shift: float, fs: int) -> float:
     """mod.rs:54-56: dt = 1.0/(fs as f64); 2.0*PI*freq_shift*dt, left to right."""
-    dt = 1.0 / float(fs)
-    return ((2.0 * math.pi) * float(freq_shift)) * dt
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dt = np.float64(1.0) / np.float64(fs)  # fs == 0 -> inf, as Rust's f64 division gives (Python's would raise)
+        return float((np.float64(2.0 * math.pi) * np.float64(freq_shift)) * dt)
+
+
+def np_from_polar(ph: float) -> complex:
+    """Complex64::from_polar(1.0, ph) (mod.rs:56): cos / sin of +-inf or NaN are NaN in IEEE arithmetic (math.cos raises)."""
+    with np.errstate(invalid="ignore"):
+        return complex(float(np.cos(np.float64(ph))), float(np.sin(np.float64(ph))))
 
 
 def np_apply_freq_shift(samples: np.ndarray, freq_shift: float, fs: int) -> np.ndarray:
     """mod.rs:46-65 -- phasor recurrence (samp *= accum; accum *= shift)."""
     ph = np_phase_step(freq_shift, fs)
-    shift = complex(math.cos(ph), math.sin(ph))
+    shift = np_from_polar(ph)
     out = np.empty(len(samples), dtype=np.complex128)
     acc = complex(1.0, 0.0)
     for i, x in enumerate(samples):
@@ -87,11 +94,12 @@ def np_apply_freq_shift(samples: np.ndarray, freq_shift: float, fs: int) -> np.n
 def np_apply_freq_shift_fast(samples: np.ndarray, freq_shift: float, fs: int) -> np.ndarray:
     """Same recurrence via cumprod (numpy's complex product == the scalar one)."""
     ph = np_phase_step(freq_shift, fs)
-    shift = complex(math.cos(ph), math.sin(ph))
+    shift = np_from_polar(ph)
     fac = np.full(len(samples), shift, dtype=np.complex128)
     if len(fac):
         fac[0] = 1.0
-    return np.asarray(samples, dtype=np.complex128) * np.cumprod(fac)
+    with np.errstate(invalid="ignore"):  # (fs == 0: NaN phasors from sample 1 on)
+        return np.asarray(samples, dtype=np.complex128) * np.cumprod(fac)
 
 
 def np_xcor(a: np.ndarray, b: np.ndarray) -> np.ndarray:

@@ -16,27 +16,25 @@ DATA = GOLDEN / "data"
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     _install_abort_trace()
-    _route_torch_copies_through_pinned_memory()
 
 
-def _route_torch_copies_through_pinned_memory():
-    """Test hygiene after the round-4 soak (profiles/r04_soak/run_24_abort.log): the one abort in 31
-    uncaptured full-suite runs was a GPU memory-access fault reported by the HSA runtime -- "Write access to a read-only page"
-    at a HOST heap address -- inside torch's `Tensor.cpu()`, i.e. in the runtime's pin-on-the-fly path for a device-to-host
-    copy into fresh PAGEABLE memory, with the device idle (a device-wide synchronize had returned and 100 ms of CPU work lay
-    in between).  None of this library's kernels or copies was running.  The tests' own result traffic therefore goes through
-    PINNED host memory (a plain DMA, no pinning of pageable ranges behind the process's back): `Tensor.cpu()` of a CUDA tensor
-    and `Tensor.cuda()` of a CPU tensor of 64 KiB or more are routed through `pin_memory`.  CAF_TESTS_PAGEABLE_COPIES=1
-    restores torch's default path (the library's own pageable-destination path, caf_surface_* into ordinary memory, is
-    exercised either way: it does not go through torch)."""
+@pytest.fixture
+def pinned_copies(monkeypatch):
+    """Opt-in, per test, undone at teardown: the -m gpu modules ask for it by name
+    (`pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pinned_copies")]`).  While it is active the TEST's own result
+    traffic -- `Tensor.cpu()` of a device tensor and `Tensor.cuda()` of a host tensor of 64 KiB or more -- goes through PINNED
+    host memory (a plain DMA) instead of the runtime's pin-on-the-fly path for pageable memory.  Why: the one abort in round
+    4's 31-run soak was a GPU page fault ("write access to a read-only page", a HOST heap address) inside torch's pageable
+    `Tensor.cpu()` with the device idle (profiles/r04_soak/run_24_abort.log); HISTORY.md "Test-run stability".  Nothing is
+    replaced at import or configure time any more, torch outside a requesting test is untouched, and
+    CAF_TESTS_PAGEABLE_COPIES=1 makes the fixture a no-op (the pageable lane of tools/soak_suite.sh).  The library's own
+    pageable-destination path (caf_surface_* into ordinary memory) is exercised either way: it does not go through torch."""
     import os
     if os.environ.get("CAF_TESTS_PAGEABLE_COPIES") == "1":
         return
     try:
         import torch
     except ImportError:
-        return
-    if getattr(torch.Tensor, "_caf_pinned_copies", False):
         return
     orig_cpu, orig_cuda = torch.Tensor.cpu, torch.Tensor.cuda
     LIMIT = 1 << 16
@@ -53,9 +51,29 @@ def _route_torch_copies_through_pinned_memory():
             return orig_cuda(self.pin_memory(), *args, **kwargs)
         return orig_cuda(self, *args, **kwargs)
 
-    torch.Tensor.cpu = cpu
-    torch.Tensor.cuda = cuda
-    torch.Tensor._caf_pinned_copies = True
+    monkeypatch.setattr(torch.Tensor, "cpu", cpu)
+    monkeypatch.setattr(torch.Tensor, "cuda", cuda)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    """One caf_ctx on GPU 0 per test module, on the PRODUCT library."""
+    import caf_cookoff_amd as caf
+    assert caf.LIB_PATH.exists(), "HIP extension missing: the product path must not run without it"
+    e = caf.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def meng():
+    """Engine on the MEASUREMENT build (libcaf_hip_measure.so): rejected kernel variants and the
+    CAF_* environment switches live only there."""
+    import caf_cookoff_amd as caf
+    assert caf.MEASURE_LIB_PATH.exists(), "measurement library missing (make -C caf_cookoff_amd/csrc)"
+    e = caf.Engine(0, lib=caf.MEASURE_LIB_PATH)
+    yield e
+    e.close()
 
 
 def _install_abort_trace():

@@ -167,6 +167,36 @@ int main(int argc, char **argv)
         }
         std::printf("test hip_multi_row_shards ... %s\n", failures == before ? "ok" : "FAILED");
     }
+    // The bench loop as ONE call (caf_multi_surface_run_batch): the five chirp pairs that share the (-100, 100, 0.25) grid of
+    // test.rs (k = 0, 3, 5, 6, 7) as one batch over three workers; the reference's answers, and every row peak value equal to
+    // the single-surface call's
+    {
+        struct K { const char *nd, *hs; double f; std::size_t idx; };
+        const K ks[5] = {{"chirp_0_raw.c64", "chirp_0_T+202samp_F+69.25Hz.c64", 69.25, 202},    // test.rs:17-30
+                         {"chirp_3_raw.c64", "chirp_3_T+151samp_F-76.22Hz.c64", -76.25, 151},   // :188-201
+                         {"chirp_5_raw.c64", "chirp_5_T+177samp_F-92.72Hz.c64", -92.75, 177},   // :226-239
+                         {"chirp_6_raw.c64", "chirp_6_T+15samp_F-49.69Hz.c64", -49.75, 15},     // :245-258
+                         {"chirp_7_raw.c64", "chirp_7_T+84samp_F+68.26Hz.c64", 68.25, 84}};     // :264-277
+        const int before = failures;
+        auto shifts = gen_float_shifts(-100.0, 100.0, 0.25);
+        std::vector<std::vector<Complex64>> nds, hss;
+        for (const K &k : ks) {
+            auto files = load_files(data_dir + k.nd, data_dir + k.hs);
+            nds.push_back(files.first);
+            hss.push_back(files.second);
+        }
+        CafHipMulti multi(std::vector<int>(3, 0), nds[0].size(), shifts, 48000);
+        std::vector<double> row_val;
+        auto peaks = multi.find_peaks_batch(nds, hss, &row_val);
+        ASSERT_EQ(peaks.size(), 5u);
+        for (std::size_t b = 0; b < 5 && b < peaks.size(); ++b) {
+            ASSERT_EQ(peaks[b].first, ks[b].f);
+            ASSERT_EQ(peaks[b].second, ks[b].idx);
+            auto want = CafHip::caf_surface(nds[b], hss[b], shifts, 48000);
+            for (std::size_t r = 0; r < want.size(); ++r) ASSERT_EQ(row_val[b * shifts.size() + r], want[r].xcor_peak_val);
+        }
+        std::printf("test hip_multi_batch ... %s\n", failures == before ? "ok" : "FAILED");
+    }
     std::printf("test result: %s. %d failed\n", failures ? "FAILED" : "ok", failures);
     return failures ? 1 : 0;
 }

@@ -38,7 +38,7 @@ def test_python_binding_covers_header(lib):
 
 def test_abi_version_and_struct_layout(lib):
     from caf_cookoff_amd import CafPeak
-    assert lib.caf_abi_version() == 3
+    assert lib.caf_abi_version() == 4
     assert ctypes.sizeof(CafPeak) == 32
 
 

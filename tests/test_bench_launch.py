@@ -92,3 +92,34 @@ def test_algorithmic_bytes_match_survey_8d():
     h = {k: bench.kernel_source_hash(k) for k in ("caf::k_seq_rows<double, 15, caf::SeqIo<double> >", "caf::k_duo_rows<float, caf::DuoIo<float> >",
                                                    "caf::k_chain_rows<float, 14, 4, 1, 0>", "")}
     assert len(set(h.values())) == 4
+
+
+def test_a_stalled_rank_ends_the_run_with_a_status_and_without_a_line():
+    """The join that cannot be skipped (mod.rs:452-457) must not be able to hang the bench: rank 1 sleeps inside the timed
+    loop, rank 0 sits in the collective waiting for it; both watchdogs fire at the phase limit, every rank writes one stderr
+    line naming its rank, device and phase, the run ends non-zero well inside the bound and NO JSON line is printed (the
+    headline was never measured)."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "4", "--plumbing-only", "--no-cpu-baseline"],
+             {"CAF_BENCH_TEST_STALL": "rank=1,phase=timed,seconds=150", "CAF_BENCH_PHASE_LIMITS": "timed=6"}, timeout=200)
+    took = time.time() - t0
+    assert r.returncode != 0, r.stdout
+    assert not _json_lines(r.stdout), r.stdout
+    assert "did not finish phase 'timed' within 6 s" in r.stderr and "without a result line" in r.stderr, r.stderr[-1500:]
+    assert "rank 1 (device cpu)" in r.stderr or "rank 0 (device cpu)" in r.stderr
+    assert took < 100, took
+    # the same run without the stall passes and carries who-sits-where and the phase clock
+    r = _run(["--gpus", "2", "--steps", "4", "--plumbing-only", "--no-cpu-baseline"], {"CAF_BENCH_PHASE_LIMITS": "timed=60"})
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = _json_lines(r.stdout)[0]
+    assert [d["rank"] for d in line["config"]["rank_devices"]] == [0, 1]
+    assert "timed" in line["extra"]["phase_seconds"] and "rank_kernel_ms_spread" in line["extra"]
+    assert "rank_kernel_ms_flag" in line["extra"]          # the fabricated kernel times (0.5 / 1.0 ms) differ by 100 %
+
+
+def test_self_launch_is_refused_under_a_profiler_preload():
+    """rocprofv3's preloaded tool library initialises the GPU before bench.py's first line: starting torchrun from such a
+    process is the exec-after-GPU-init this pool forbids.  --in-process / --emulate-rank-of are the ways to profile."""
+    r = _run(["--gpus", "2", "--plumbing-only"], {"ROCPROFILER_TOOL_TEST_MARKER": "1"})
+    assert r.returncode == 2 and "--emulate-rank-of" in r.stderr and not _json_lines(r.stdout)

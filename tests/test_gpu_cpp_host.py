@@ -25,7 +25,7 @@ def test_cpp_kats(built):
                        text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("... ok") == 16 and "test result: ok. 0 failed" in r.stdout
+    assert r.stdout.count("... ok") == 17 and "test result: ok. 0 failed" in r.stdout
 
 
 def test_cpp_main_demo(built):

@@ -6,6 +6,21 @@
 set -o pipefail
 O=${1:?output dir}; shift
 EXTRA=("$@")
+# A profiled bench.py must not start other GPU programs: rocprofv3's preload initialises the GPU before bench.py runs, and
+# `--gpus N > 1` would start torchrun from that process.  Profile a rank's launch shape with --emulate-rank-of N, or the
+# one-process multi-device path with --in-process.
+gpus=1; safe=0
+for ((i = 0; i < ${#EXTRA[@]}; i++)); do
+    case "${EXTRA[i]}" in
+        --gpus) gpus=${EXTRA[i+1]:-1} ;;
+        --gpus=*) gpus=${EXTRA[i]#--gpus=} ;;
+        --in-process|--emulate-rank-of|--emulate-rank-of=*) safe=1 ;;
+    esac
+done
+if [ "$gpus" -gt 1 ] && [ "$safe" -ne 1 ]; then
+    echo "profile_run.sh: refusing --gpus $gpus under rocprofv3 without --in-process or --emulate-rank-of (see the comment above)" >&2
+    exit 4
+fi
 B="$PWD/bench.py"
 mkdir -p "$O"
 export TMPDIR=/tmp
