@@ -139,7 +139,7 @@ def self_launch(args) -> int:
 # ------------------------------------------------------------------------------ the line --
 LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "extra")
-ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel",
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_is", "traffic_source", "kernel",
                  "kernel_ms", "launches_timed", "algorithmic_bytes_per_launch", "frac_of_achievable_6.29TBs", "whole_step_frac")
 MULTI_EXTRA_KEYS = ("rank_kernel_ms", "rccl_world", "headline_blocks", "configs3_c64_sharded", "configs4_stream_surface_parallel")
 KERNEL_SPREAD_FLAG = 0.10   # extra.rank_kernel_ms_flag when (max - min) / min of the ranks' row-kernel times exceeds this

@@ -97,10 +97,32 @@ def profiled_traffic(kernel_name: str, nsurf: int, dtype: str, abytes=None):
                 t.get("dtype") == ("f64" if dtype == "c128" else "f32") and \
                 (abytes is None or t.get("algorithmic_bytes_per_launch") in (None, abytes)):  # same rows per launch too
             if t.get("source_hash") == here:
-                best = (t["traffic_bytes_per_launch"], str(f.relative_to(ROOT)))
+                best = (t["traffic_bytes_per_launch"], str(f.relative_to(ROOT)), t)
             else:
                 stale = str(f.relative_to(ROOT))
     return best, stale
+
+
+def traffic_detail(kernel_name: str, nsurf: int, dtype: str, abytes=None):
+    """What the committed profile of this launch shape says beyond the byte count: the L2's memory-side request counters
+    (profiles/*/traffic.json `fabric`), whether an HBM / Infinity-Cache split exists (`hbm_bytes_per_launch`, `hbm_split`) and,
+    where tools/traffic_components.py has run, which buffers the bytes consist of -- each only under the source-hash rule."""
+    best, _ = profiled_traffic(kernel_name, nsurf, dtype, abytes)
+    if not best:
+        return None
+    t, src = best[2], Path(best[1])
+    out = {"source": str(src), "hbm_bytes_per_launch": t.get("hbm_bytes_per_launch"), "hbm_split": t.get("hbm_split"),
+           "fabric": t.get("fabric")}
+    comp = ROOT / src.parent / "traffic_components.json"
+    if comp.exists():
+        try:
+            c = json.loads(comp.read_text())
+            if c.get("source_hash") == kernel_source_hash(kernel_name):
+                out["components"] = c.get("components")
+                out["components_source"] = str(comp.relative_to(ROOT))
+        except (OSError, ValueError):
+            pass
+    return out
 
 
 def host_cpu_info():
@@ -199,6 +221,8 @@ def traffic_fields(kernel_name, nsurf, dtype, abytes):
     traffic, stale = profiled_traffic(kernel_name, nsurf, dtype, abytes)
     return {"traffic": traffic[0] if traffic else None,
             "traffic_over_algorithmic": traffic[0] / abytes if traffic else None,
+            "traffic_is": "bytes that leave L2 (misses + write-backs: 2 x FETCH_SIZE + WRITE_SIZE); whether the Infinity Cache or an HBM "
+                          "channel serves them is not exposed by rocprofv3 on gfx950 (no MALL / UMC counter)",
             "traffic_source": (traffic[1] + " (rocprofv3 PMC passes of this command, collected offline; "
                                "kernel-source hash matches)") if traffic else
                               (f"none: {stale} was measured on other kernel sources" if stale else None)}

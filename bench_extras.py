@@ -11,7 +11,7 @@ import sys
 import time
 
 from bench_common import (FS, HBM_PEAK_GBS, N_SAMP, ROOT, Case, algorithmic_bytes, host_cpu_info, roofline_entry, secondary_entry,
-                          traffic_fields)
+                          traffic_detail, traffic_fields)
 
 
 def cpu_baseline(seconds: float, max_threads: int):
@@ -519,6 +519,9 @@ def n1_extras(args, eng, torch, dev, local_rank, freqs, K, extra):
                            "kernel": c.plan.kernel_name, "kernel_path": c.plan.path, "kernel_ms": kms,
                            "algorithmic_bytes": ab, "achieved_GBs": e["achieved"], "frac": e["frac"]}
             extra[name].update(traffic_fields(c.plan.kernel_name, batch, dtype, ab))
+            det = traffic_detail(c.plan.kernel_name, batch, dtype, ab)
+            if det:
+                extra[name]["traffic_detail"] = det
             if ceiling and not args.no_ceiling:
                 bound, env, how = ceiling
                 try:

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import DATA
-from gpu_common import FS, TOL32, TOL64, _dev_view, _planted
+from gpu_common import FS, TOL32, TOL64, _dev_view, _pair, _planted
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pinned_copies")]
 
@@ -326,7 +326,7 @@ def test_multi_batch_bit_equal_to_unsharded_batch(B, devices, eng, oracle):
     ridx, rval, peaks = ms.run_batch(nd, hs)
     _check_batch_against_unsharded(ms, devices, ref, ridx, rval, peaks, fr, 4096, "c128")
     assert np.array_equal(peaks["idx"], np.asarray(lags))
-    assert np.all(np.abs(peaks["freq"] - np.asarray(fos)) <= 0.25 + 1e-9)
+    assert np.all(np.abs(peaks["freq"] - np.asarray(fos)) <= 0.5 + 1e-9)      # (bench.py's own gate on the 0.5 Hz grid)
     r2, v2, p2 = ms.run_batch(batch=B)                       # needles = haystacks = NULL: the pairs already on the devices
     assert np.array_equal(r2, ridx) and np.array_equal(v2, rval) and p2.tobytes() == peaks.tobytes()
     _, _, p3 = ms.run_batch(batch=B, want_rows=False)        # row records stay on the devices

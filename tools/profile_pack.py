@@ -63,5 +63,29 @@ if fetch is not None and write is not None:
             "surfaces_per_launch": bench.get("config", {}).get("surfaces_per_step"),
             "dtype": bench.get("dtype"), "algorithmic_bytes_per_launch":
                 bench.get("roofline", {}).get("algorithmic_bytes_per_launch")}
+    # The L2's memory-side (fabric) request counters by size and destination, when the pmc_ea_* passes were taken.  They say how
+    # much leaves L2 and that it is all bound for the memory side (DRAM, as opposed to GMI / IO); whether the Infinity Cache
+    # or an HBM channel then serves a request is invisible from here: rocprofv3 lists no MALL and no UMC counter on gfx950.
+    ea = {c: mean_counter(pat, c) for pat, cs in (("pmc_ea_rd", ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_BUBBLE_sum")),
+                                                  ("pmc_ea_wr", ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_EA0_WRREQ_DRAM_sum")),
+                                                  ("pmc_l2", ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"))) for c in cs}
+    if ea.get("TCC_EA0_RDREQ_sum") is not None and ea.get("TCC_EA0_WRREQ_sum") is not None:
+        rd, rd32, rdd, bub = (ea[k] or 0.0 for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_BUBBLE_sum"))
+        wr, wr64, wrd = (ea[k] or 0.0 for k in ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_EA0_WRREQ_DRAM_sum"))
+        info["fabric"] = {
+            "counters": ea,
+            # rocprofv3's own derived-metric expression for read bytes: 128-B "bubble" requests, 64-B and 32-B requests
+            "read_bytes_by_request_size": bub * 128 + (rd - bub - rd32) * 64 + rd32 * 32,
+            "write_bytes_by_request_size": wr64 * 64 + (wr - wr64) * 32,
+            "read_requests_bound_for_dram": rdd / rd if rd else None,
+            "write_requests_bound_for_dram": wrd / wr if wr else None,
+            "l2_hit_rate": (ea["TCC_HIT_sum"] / (ea["TCC_HIT_sum"] + ea["TCC_MISS_sum"])) if ea.get("TCC_HIT_sum") is not None and
+                           (ea["TCC_HIT_sum"] + ea["TCC_MISS_sum"]) else None}
+    info["hbm_bytes_per_launch"] = None
+    info["hbm_split"] = ("not exposed: rocprofv3 --list-avail on gfx950 (profiles/r05_counters/) offers the blocks SQ, SQC, TA, TD, TCP, TCC, "
+                         "TCA, SPI, GRBM, CPC, CPF only -- no MALL / Infinity-Cache hit counter and no UMC (HBM channel) counter; "
+                         "TCC_EA0_*_DRAM count requests BOUND for the memory side, which the Infinity Cache serves or passes on "
+                         "invisibly.  traffic_bytes_per_launch is therefore fabric traffic (L2 misses and write-backs); see "
+                         "traffic_components.json, where one exists, for which buffers it consists of")
     (dst / "traffic.json").write_text(json.dumps(info, indent=1) + "\n")
     print(json.dumps(info))
