@@ -82,7 +82,7 @@ def issue_ceiling(torch, dev, case, env, steps=10):
                          and stores removed -> what remains is the VALU instruction stream of the row
       chain kernels      CAF_CHAIN_ABL=31 (configs[3]): no global memory, no workgroup barriers; the LDS
                          exchanges of the chain stay (without them the values would have to live in registers
-                         and the kernel spills: DESIGN.md section 5)
+                         and the kernel spills: HISTORY.md section 5)
     -> kernel ms per launch, or None."""
     import caf_cookoff_amd as caf
     if not caf.MEASURE_LIB_PATH.exists():

@@ -1,7 +1,7 @@
 // kernels_lanehalf4096.hpp -- MEASUREMENT LIBRARY ONLY (-DCAF_MEASURE, CAF_ROW_KERNEL=1): the first tuned n = 4096 row
 // kernel of round 1, k_fused_rows -- 512 threads per row, the even- and odd-bin chains of a row in the two lane halves
 // of every wave, joined by v_permlane32_swap.  It runs at the speed of the product kernel k_seq_rows (kernels_seq4096.hpp;
-// DESIGN.md section 5) and carries the only stamped (s_memtime) build left, tools/stamps.py.  The haystack spectrum it
+// HISTORY.md section 5) and carries the only stamped (s_memtime) build left, tools/stamps.py.  The haystack spectrum it
 // reads is the product's (k_seq_prepare).  Moved out of kernels_fused4096.hpp in round 3 so that the product headers
 // hold product code only.
 //

@@ -215,7 +215,7 @@ int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, 
  * staged into device memory by the spectrum launch, find_peak writes the row peaks and the
  * caf_peak records out) -- no copy-engine nodes.  While slot k computes, the caller fills slot
  * k+1's pinned buffers and submits it: its input transfer overlaps slot k's kernels.  Three or
- * four slots sustain the most single-surface replays per second on MI355X (the
+ * four slots sustain the most single-surface replays per second on MI355X (HISTORY.md section 9; the
  * slot streams are probed at creation so that they sit on separate hardware queues), but that rate
  * depends on how the runtime arbitrates the slot streams' hardware queues; batch = 8 with four slots
  * is the fastest form measured and the one that keeps its rate from creation to creation

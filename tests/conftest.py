@@ -78,7 +78,7 @@ def meng():
 
 def _install_abort_trace():
     """tests/cpp/abort_trace.c: if a native library under the tests calls abort(), print the native stack before
-    faulthandler's Python stacks.  Installed after pytest's own faulthandler set-up, so this
+    faulthandler's Python stacks (HISTORY.md section 10).  Installed after pytest's own faulthandler set-up, so this
     handler runs first and then hands over to it.  Missing helper (not built): nothing happens."""
     import ctypes
     so = ROOT / "tests" / "cpp" / "abort_trace.so"

@@ -1,7 +1,7 @@
 /* abort_trace.c -- test infrastructure (loaded by tests/conftest.py, never by the product): when the process receives
  * SIGABRT -- a runtime library calling abort() under it, which Python's faulthandler can only report as "Fatal Python
  * error: Aborted" with the PYTHON stacks -- write the NATIVE stack of the aborting thread to stderr first, then hand
- * the signal to whoever handled it before (faulthandler, then the default action).  DESIGN.md section 10: two silent
+ * the signal to whoever handled it before (faulthandler, then the default action).  HISTORY.md section 10: two silent
  * aborts in some seventy full GPU runs had no message at all; the next one will at least say where it came from.
  * build: gcc -O1 -g -shared -fPIC -o abort_trace.so abort_trace.c */
 #define _GNU_SOURCE

@@ -300,7 +300,7 @@ def test_r32_variant_matches_oracle_and_product_kernel(eng, oracle, monkeypatch)
     """kernels_r32.hpp (16384 = 32 x 32 x 16, 512 threads, two LDS exchanges per transform) lives
     in the MEASUREMENT library (CAF_R32=1): parity-green against the oracle, row argmax and peak equal to the product
     chain kernel's on a multi-row launch that wraps the persistent grid (300 rows > 256 workgroups), and
-    bit-identical from run to run.  It runs at the product kernel's speed, not faster -- DESIGN.md section 5."""
+    bit-identical from run to run.  It runs at the product kernel's speed, not faster -- HISTORY.md section 5."""
     import torch
     import caf_cookoff_amd as caf
     from caf_cookoff_amd.synth import make_pair

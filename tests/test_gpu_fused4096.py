@@ -322,7 +322,7 @@ def test_ragged_shard_batches_both_row_assignments(eng, oracle):
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3], ids=["sequential", "lane-half", "radix8", "two-chain"])
 def test_row_kernel_variants_agree(variant, meng, oracle, golden, monkeypatch):
-    """All four n = 4096 row kernels (CAF_ROW_KERNEL of the MEASUREMENT library)
+    """All four n = 4096 row kernels (CAF_ROW_KERNEL of the MEASUREMENT library, HISTORY.md section 5)
     produce the reference's answer: the product uses 0 for complex128 and 3 for complex64, the
     others are measurement variants and must stay parity-green."""
     eng = meng

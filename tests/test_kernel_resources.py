@@ -1,6 +1,6 @@
 """Compile-time guard for the two product row kernels (CPU, no GPU needed): hipcc's
 kernel-resource-usage remarks must show the register/occupancy shape the launch code and the
-measurements in DESIGN.md section 5 assume.  The f64 kernel sits exactly at the 256-VGPR limit,
+measurements in HISTORY.md section 5 assume.  The f64 kernel sits exactly at the 256-VGPR limit,
 where an innocent source change can flip the allocator into tens of spills (a wave-uniform store
 offset moved to the SGPR operand did: 0 -> 50 spills)."""
 import re
@@ -47,7 +47,7 @@ def test_chain_kernels_register_shape():
     constants became SGPR operands; the R = 4 complex64 kernel (BASELINE configs[3]) sits at
     35 spilled registers (90 before the load/store optimizer was switched off for this kernel family) and
     the R = 8 kernels (six live slab descriptors + the W_128 combine; chain pairs as a run-time loop) at 59 / 74, known costs
-     that must not get worse silently."""
+    (HISTORY.md section 5) that must not get worse silently."""
     usage = _usage()
     seen = 0
     for name, f in usage.items():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/soak_suite.sh RUNS OUTDIR [FIRST_INDEX] [pageable]
-# The abort hunt of DESIGN.md section 10: RUNS consecutive full `pytest -m gpu` runs, ONE process at a time, uncaptured
+# The abort hunt of HISTORY.md section 10: RUNS consecutive full `pytest -m gpu` runs, ONE process at a time, uncaptured
 # (--capture=no: whatever the HIP / HSA runtime prints to fd 2 before an abort() lands in the log instead of in pytest's
 # capture buffer) with AMD_LOG_LEVEL=1 (runtime errors only), the whole log kept per run.  tests/conftest.py installs the
 # native-stack SIGABRT handler (tests/cpp/abort_trace.so).  A run that hits its time limit ends the soak: no further GPU

@@ -1,5 +1,5 @@
 // unregister_probe.hip -- what does the HIP runtime still know about a heap block after hipHostUnregister?
-// (the one GPU page fault of the round-4 soak was a write of the runtime's own pageable D2H copy to
+// (HISTORY.md section 10: the one GPU page fault of the round-4 soak was a write of the runtime's own pageable D2H copy to
 // a HOST heap address; hypothesis: a heap block that was registered, unregistered, freed and handed out again by malloc.)
 // This probe only QUERIES the runtime (hipPointerGetAttributes, hipHostGetDevicePointer): no kernel, no copy, nothing
 // that could fault.  Build: hipcc -O2 -o unregister_probe unregister_probe.hip
