@@ -132,7 +132,7 @@ def host_api_times(reps=200):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def stream_run(plan, nd, hs, lags, total, nslots, batch, split, three_kernels=False, native=True, passes=5):
+def stream_run(plan, nd, hs, lags, total, nslots, batch, split, three_kernels=False, native=True, passes=5, memcpy_nodes=False):
     """`total` surfaces through a caf_stream.  native: the whole loop is one caf_stream_run call (fill the
     slot's pinned buffers, replay its graph, retire the oldest slot -- in C++, as a compiled host would);
     otherwise the same loop step by step from Python (submit / wait per slot), which adds ~10 us of
@@ -140,7 +140,8 @@ def stream_run(plan, nd, hs, lags, total, nslots, batch, split, three_kernels=Fa
     import numpy as np
     import caf_cookoff_amd as caf
     pool_n = len(lags)
-    st = caf.Stream(plan, batch=batch, nslots=nslots, want_surface=True, split=split, three_kernels=three_kernels)
+    st = caf.Stream(plan, batch=batch, nslots=nslots, want_surface=True, split=split, three_kernels=three_kernels,
+                    memcpy_nodes=memcpy_nodes)
     best, ok = None, 0
     if native:
         reps = (total + pool_n - 1) // pool_n
@@ -201,6 +202,11 @@ def stream_case(eng, torch, freqs, total=1000):
       split4_2slots                   four independent single-surface chains per replay
       batched4_2slots / batched8_4slots   one batched chain of four / eight surfaces per replay (coarser granularity:
                                       60-62 k surfaces/s with eight per replay and four slots, tools/stream_batch_sweep.py)
+      batched8_4slots_memcpy_nodes / batched1_2slots_memcpy_nodes
+                                      BASELINE configs[4] TO THE LETTER: the inputs cross PCIe as hipMemcpyAsync (copy-engine) nodes of
+                                      the slot's graph into device buffers, the results come back as hipMemcpyAsync nodes
+                                      (CAF_STREAM_MEMCPY_NODES); eight surfaces per replay on four slots, and the plain
+                                      double-buffered form: one surface per replay on two slots
       single_2slots_three_kernels     round-2a form {spectrum, rows, find_peak} as three nodes (for comparison)
       single_2slots_python_loop       submit / wait driven from Python, step by step (for comparison)
     `value` = the FIXED form batched8_4slots (eight surfaces per graph replay, four slots): the fastest form AND the one
@@ -212,14 +218,16 @@ def stream_case(eng, torch, freqs, total=1000):
     plan = eng.plan(N_SAMP, freqs, FS)
     nd, hs, lags, _ = make_batch(64, N_SAMP, FS, seed0=5000)
     forms = {}
-    for name, nslots, batch, split, three, native in (
-            ("single_2slots", 2, 1, False, False, True), ("single_3slots", 3, 1, False, False, True),
-            ("single_4slots", 4, 1, False, False, True),
-            ("split4_2slots", 2, 4, True, False, True), ("batched4_2slots", 2, 4, False, False, True),
-            ("batched8_4slots", 4, 8, False, False, True),
-            ("single_2slots_three_kernels", 2, 1, False, True, True),
-            ("single_2slots_python_loop", 2, 1, False, False, False)):
-        v, us, okc = stream_run(plan, nd, hs, lags, total, nslots, batch, split, three, native)
+    for name, nslots, batch, split, three, native, mc in (
+            ("single_2slots", 2, 1, False, False, True, False), ("single_3slots", 3, 1, False, False, True, False),
+            ("single_4slots", 4, 1, False, False, True, False),
+            ("split4_2slots", 2, 4, True, False, True, False), ("batched4_2slots", 2, 4, False, False, True, False),
+            ("batched8_4slots", 4, 8, False, False, True, False),
+            ("batched8_4slots_memcpy_nodes", 4, 8, False, False, True, True),
+            ("batched1_2slots_memcpy_nodes", 2, 1, False, False, True, True),
+            ("single_2slots_three_kernels", 2, 1, False, True, True, False),
+            ("single_2slots_python_loop", 2, 1, False, False, False, False)):
+        v, us, okc = stream_run(plan, nd, hs, lags, total, nslots, batch, split, three, native, memcpy_nodes=mc)
         forms[name] = {"value": v, "us_per_surface": us, "tau_correct": okc}
         if native:
             forms[name]["host_thread"] = dict(getattr(stream_run, "last_host_us", {}))
@@ -229,10 +237,13 @@ def stream_case(eng, torch, freqs, total=1000):
     best = "batched8_4slots"
     return {"workload": f"{total} back-to-back 400x8192 complex128 surfaces from host memory, hipGraph replay per slot, "
                         "stage-in of inputs and stage-out of peaks included, surfaces left on the device (BASELINE configs[4]); "
-                        "the kernels read and write mapped pinned host memory in place (no hipMemcpyAsync / copy-engine nodes)",
+                        "`value`: the kernels read and write mapped pinned host memory in place; the literal form of the config text "
+                        "(hipMemcpyAsync nodes both ways) is reported beside it as forms.batched8_4slots_memcpy_nodes / "
+                        "batched1_2slots_memcpy_nodes and as `memcpy_nodes_value`",
             "value": forms[best]["value"], "unit": "surfaces/s", "form": best, "forms": forms,
             "value_is": f"median of {forms[best].get('passes')} passes over the {total} pairs (one more pass before them warms up)",
             "value_min": forms[best].get("value_min"), "value_max": forms[best].get("value_max"),
+            "memcpy_nodes_value": forms["batched8_4slots_memcpy_nodes"]["value"],
             "algorithmic_bytes_per_surface": abytes, "frac": abytes * forms[best]["value"] / 1e9 / HBM_PEAK_GBS}
 
 
@@ -553,6 +564,9 @@ def n1_extras(args, eng, torch, dev, local_rank, freqs, K, extra):
         extra["configs4_stream"]["multi_ctx2_same_gpu"] = multi_stream_case(freqs, [local_rank, local_rank], total=1000)
     except Exception as e:
         extra["error"] = f"{type(e).__name__}: {e}"
+    # (a child process, timed from C: before the in-process legs below, whose 13 GB of slab allocations and frees would otherwise
+    #  sit between it and the streaming measurements it has always followed)
+    extra["host_api"] = host_api_times()
     try:
         extra["in_process_multi"] = in_process_config3([local_rank], steps=10, warmup=2, forms=("host_join", "rccl_join"))
         extra["in_process_multi"]["two_contexts_same_gpu"] = in_process_config3(
@@ -561,8 +575,7 @@ def n1_extras(args, eng, torch, dev, local_rank, freqs, K, extra):
         extra["in_process_multi"] = {"error": f"{type(e).__name__}: {e}"}
     try:
         # the headline itself through the C ABI's batched row-shard call (what `bench.py --in-process` times), RCCL join with one rank
-        extra["in_process_headline"] = in_process_headline([local_rank], args.batch, steps=max(5, min(K, 30)), warmup=2,
+        extra["in_process_headline"] = in_process_headline([local_rank], args.batch, steps=max(5, min(K, 30)), warmup=5,
                                                            forms=("rccl_join", "host_join"), check=not args.no_check)
     except Exception as e:
         extra["in_process_headline"] = {"error": f"{type(e).__name__}: {e}"}
-    extra["host_api"] = host_api_times()

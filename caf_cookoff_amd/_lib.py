@@ -32,6 +32,7 @@ CAF_STREAM_SPLIT = 1
 CAF_STREAM_THREE_KERNELS = 2
 CAF_STREAM_TWO_KERNELS = 4
 CAF_STREAM_ONE_KERNEL = 8
+CAF_STREAM_MEMCPY_NODES = 16
 CAF_MULTI_REDUCE_RCCL = 1
 CAF_MULTI_SURFACE_ON_DEVICE = 2
 

@@ -339,19 +339,22 @@ class Stream:
     PEAK_DTYPE = np.dtype([("val", "<f8"), ("freq", "<f8"), ("idx", "<u8"), ("row", "<i8")])
 
     def __init__(self, plan: "Plan", batch: int, nslots: int = 2, want_surface: bool = True, split: bool = False,
-                 three_kernels: bool = False, two_kernels: bool = False, one_kernel: bool = False):
+                 three_kernels: bool = False, two_kernels: bool = False, one_kernel: bool = False, memcpy_nodes: bool = False):
         """``split``: the slot's graph holds ``batch`` independent single-surface node chains
         (CAF_STREAM_SPLIT) instead of one batched chain.  Single-surface chains of n = 4096 plans are one
         launch or two kernel nodes, chosen by the number of surfaces in flight (include/caf_hip.h);
         ``one_kernel`` / ``two_kernels`` force either, ``three_kernels`` keeps the older
-        {spectrum, rows, find_peak} chain (for comparison)."""
+        {spectrum, rows, find_peak} chain (for comparison).  ``memcpy_nodes``: inputs and results cross PCIe as
+        hipMemcpyAsync nodes of the graph (BASELINE configs[4] to the letter) instead of kernels reading / writing the
+        mapped pinned buffers in place."""
         self.plan, self.batch, self.nslots = plan, int(batch), int(nslots)
         h = ctypes.c_void_p()
         plan.eng._check(plan.eng.lib.caf_stream_create_ex(plan._h, self.batch, self.nslots, int(bool(want_surface)),
                                                           (_lib.CAF_STREAM_SPLIT if split else 0)
                                                           | (_lib.CAF_STREAM_THREE_KERNELS if three_kernels else 0)
                                                           | (_lib.CAF_STREAM_TWO_KERNELS if two_kernels else 0)
-                                                          | (_lib.CAF_STREAM_ONE_KERNEL if one_kernel else 0),
+                                                          | (_lib.CAF_STREAM_ONE_KERNEL if one_kernel else 0)
+                                                          | (_lib.CAF_STREAM_MEMCPY_NODES if memcpy_nodes else 0),
                                                           ctypes.byref(h)))
         self._h = h
         plan._streams.add(self)

@@ -247,7 +247,11 @@ enum caf_stream_flags {
     CAF_STREAM_SPLIT = 1,
     CAF_STREAM_THREE_KERNELS = 2,
     CAF_STREAM_TWO_KERNELS = 4,
-    CAF_STREAM_ONE_KERNEL = 8
+    CAF_STREAM_ONE_KERNEL = 8,
+    /* BASELINE configs[4] to the letter: the slot's inputs cross PCIe as hipMemcpyAsync (copy-engine) nodes of the graph into
+     * device buffers and the peaks / row records come back as hipMemcpyAsync nodes, instead of kernels reading and writing the
+     * mapped pinned buffers in place (the default, faster: bench.py reports both).  Batched chains only. */
+    CAF_STREAM_MEMCPY_NODES = 16
 };
 int caf_stream_create_ex(caf_plan *plan, size_t batch, int nslots, int want_surface, unsigned flags,
                          caf_stream **out);

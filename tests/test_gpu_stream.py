@@ -345,3 +345,31 @@ def test_small_path_streaming_slots(n, dtype, split, eng, oracle):
         order = np.sort(oval)
         if order[-1] - order[-2] > 4 * tol * oval.max():
             assert int(peaks[k]["row"]) == int(np.argmax(oval))
+
+
+
+@pytest.mark.parametrize("dtype,n,batch,nslots", [("c128", 4096, 8, 4), ("c128", 4096, 1, 2), ("c64", 4096, 3, 2), ("c64", 2048, 2, 2),
+                                                  ("c128", 64, 5, 3)])
+def test_stream_memcpy_nodes_form_equals_mapped_form(dtype, n, batch, nslots, eng, oracle):
+    """CAF_STREAM_MEMCPY_NODES (BASELINE configs[4] to the letter: hipMemcpyAsync nodes carry the inputs in and the results out)
+    returns the same bits as the default form (kernels read / write the mapped pinned buffers) for the same batched chain, and
+    the planted peaks; a ragged last replay included."""
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd.synth import make_batch
+    cdt = np.complex128 if dtype == "c128" else np.complex64
+    fr = np.linspace(-100.0, 100.0, 80, endpoint=False)   # (make_batch plants its offsets within +-100 Hz)
+    count = 3 * batch * nslots + 1
+    nd, hs, lags, _ = make_batch(count, n, FS, seed0=9100, dtype=cdt)
+    plan = eng.plan(n, fr, FS, dtype=dtype)
+    res = {}
+    for mc in (False, True):
+        st = caf.Stream(plan, batch=batch, nslots=nslots, want_surface=True, memcpy_nodes=mc, two_kernels=(batch == 1 and not mc))
+        res[mc] = st.run(nd, hs, want_rows=True)
+        st.close()
+    (p0, i0, v0), (p1, i1, v1) = res[False], res[True]
+    assert np.array_equal(p1["idx"], np.asarray(lags)) and np.array_equal(i0, i1)
+    if batch > 1:   # the same batched kernels either way: bit-equal; batch 1 of n = 4096 compares the one-launch surface with the batched kernels
+        assert p0.tobytes() == p1.tobytes() and np.array_equal(v0, v1)
+    else:
+        assert np.array_equal(p0["idx"], p1["idx"]) and np.array_equal(p0["row"], p1["row"]) and np.allclose(v0, v1, rtol=1e-12, atol=0)
+    plan.close()
