@@ -239,8 +239,11 @@ class PhaseWatchdog:
     phase) runs first, under `line_lock`: the extras phases use it to print the headline that was measured BEFORE the hang.
     Limits (seconds) can be overridden for tests: CAF_BENCH_PHASE_LIMITS="timed=5,warmup=5"."""
 
-    LIMITS = {"rendezvous": 150.0, "setup": 300.0, "warmup": 120.0, "check": 120.0, "timed": 180.0, "blocks": 300.0,
-              "ceiling": 180.0, "extras": 900.0, "multi_extras": float(EXTRAS_LIMIT_S), "cpu_baseline": 180.0, "finish": 120.0}
+    # (a healthy default run spends < 1 s in each of the first five, ~8 s in the blocks, ~10 s in the N = 1 extras; the limits
+    #  are sized so that a rank stuck in any ONE phase leaves well inside a 600-second outer limit)
+    LIMITS = {"rendezvous": 150.0, "setup": 180.0, "warmup": 120.0, "check": 90.0, "timed": 150.0, "blocks": 180.0,
+              "ceiling": 120.0, "extras": 420.0, "multi_extras": float(EXTRAS_LIMIT_S), "cpu_baseline": 120.0, "finish": 90.0,
+              "in_process_timed": 300.0}
 
     def __init__(self, rank: int, device):
         self.rank, self.device = rank, device

@@ -123,3 +123,30 @@ def test_self_launch_is_refused_under_a_profiler_preload():
     process is the exec-after-GPU-init this pool forbids.  --in-process / --emulate-rank-of are the ways to profile."""
     r = _run(["--gpus", "2", "--plumbing-only"], {"ROCPROFILER_TOOL_TEST_MARKER": "1"})
     assert r.returncode == 2 and "--emulate-rank-of" in r.stderr and not _json_lines(r.stdout)
+
+
+def test_watchdog_prints_the_measured_headline_before_leaving():
+    """A hang AFTER the timed region costs the run its status but not the measurement: the phase's on_expiry callback runs under
+    the line lock (it prints the headline snapshot once), then the process writes its stderr line and leaves with status 3; a
+    phase without a callback leaves without any line."""
+    code = r'''
+import sys, time
+sys.path.insert(0, %r)
+import bench_common as bc
+bc.guard_stdout()
+wd = bc.PhaseWatchdog(3, "cuda:3")
+wd.limits["extras"] = 1.0
+def cb():
+    if not wd.printed:
+        wd.printed = True
+        bc.emit_line({"value": 1.0, "extra": {"error": "extras hung"}})
+wd.enter("setup"); wd.enter("timed"); wd.enter("extras", on_expiry=cb if sys.argv[1] == "cb" else None)
+time.sleep(30)
+''' % str(ROOT)
+    for mode, want_line in (("cb", True), ("none", False)):
+        r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 3, (r.returncode, r.stderr)
+        assert "rank 3 (device cuda:3) did not finish phase 'extras' within 1 s" in r.stderr
+        lines = _json_lines(r.stdout)
+        assert (len(lines) == 1 and lines[0]["extra"]["error"] == "extras hung") if want_line else not lines
+        assert ("without a result line" in r.stderr) == (not want_line)
