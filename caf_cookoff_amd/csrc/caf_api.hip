@@ -62,6 +62,7 @@ template <typename T> static bool measure_plan_tables(caf_plan *, int *) { retur
 template <typename T> static void measure_fused_args(const caf_plan *, FusedArgs<T> &) {}
 template <typename T> static bool measure_fused_prepare(caf_plan *, FusedArgs<T> &, size_t) { return false; }
 static void measure_fused_tuning(bool *, size_t *) {}
+static void measure_grid_reserve(size_t *) {}
 template <typename T> static bool measure_fused_rows(caf_plan *, FusedArgs<T> &, unsigned, size_t, int *) { return false; }
 template <typename T> static bool measure_chain_rows(caf_plan *, ChainArgs<T> &, const cpx<T> *, unsigned, int, int *) { return false; }
 static bool measure_surface_dev(caf_plan *, const void *, const void *, size_t, void *, uint64_t *, void *, int *) { return false; }
