@@ -150,3 +150,14 @@ time.sleep(30)
         lines = _json_lines(r.stdout)
         assert (len(lines) == 1 and lines[0]["extra"]["error"] == "extras hung") if want_line else not lines
         assert ("without a result line" in r.stderr) == (not want_line)
+
+
+def test_four_ranks_plumbing_only():
+    """world size 4 (400 rows -> 100 per rank; 4096 rows -> 1024; 1000 pairs -> 250): the launcher, the rendezvous, both peak
+    reductions and the per-rank bookkeeping of the line at a world size that is neither 1 nor 2."""
+    r = _run(["--gpus", "4", "--steps", "3", "--plumbing-only", "--no-cpu-baseline"], timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    (line,) = _json_lines(r.stdout)
+    assert line["n_gpus"] == 4 and line["config"]["rows_per_gpu"] == 100 and line["config"]["surfaces_per_step"] == 4 * 256
+    assert [d["rank"] for d in line["config"]["rank_devices"]] == [0, 1, 2, 3] and len(line["extra"]["rank_kernel_ms"]) == 4
+    assert line["extra"]["configs3_c64_sharded"]["rows_rank0"] == 1024 and line["extra"]["configs4_stream_surface_parallel"]["pairs_rank0"] == 250
