@@ -1,0 +1,98 @@
+// C++ counterpart of the reference's multi-thread bench (caf_rust/benches/caf_bench.rs:150-168, bench_rustfft_threadpool): the
+// chirp_0 pair, 400 shifts -100 ... 99.5 Hz (caf_bench.rs:26-35), fs = 48000 -- through the C ABI only, as a compiled host
+// reaches the engine:
+//   (1) the literal loop: one caf_surface + find_peak per iteration (host pointers, the 26 MB surface back as row Vecs)
+//   (2) the same call peaks-only (caf_surface_c128 with surface = NULL)
+//   (3) the loop handed over as ONE call per B pairs: caf_multi_surface_run_batch on every visible GPU (Doppler rows sharded
+//       over the GPUs, surfaces kept in HBM, peaks joined by in-library RCCL when there is more than one GPU), uploading the
+//       pairs with every call and from HBM
+// usage: caf_bench [data_dir] [B = 256] [calls = 20]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+
+#include "caf_hip.hpp"
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char **argv)
+{
+    using namespace caf;
+    const std::string dir = argc > 1 ? argv[1] : "tests/golden/data";
+    const std::size_t B = argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 256;
+    const int calls = argc > 3 ? std::atoi(argv[3]) : 20;
+    auto files = load_files(dir + "/chirp_0_raw.c64", dir + "/chirp_0_T+202samp_F+69.25Hz.c64");
+    const auto &needle = files.first, &hay = files.second;
+    const std::size_t n = needle.size();
+    std::vector<double> shifts;
+    for (int m = -100000; m < 100000; m += 500) shifts.push_back(m / 1e3);
+
+    // (1) the literal loop
+    std::pair<double, std::size_t> pk;
+    for (int i = 0; i < 3; ++i) pk = CafHip::find_peak(CafHip::caf_surface(needle, hay, shifts, 48000));
+    double t0 = now_s();
+    const int lit = 10;
+    for (int i = 0; i < lit; ++i) pk = CafHip::find_peak(CafHip::caf_surface(needle, hay, shifts, 48000));
+    const double ms_literal = (now_s() - t0) / lit * 1e3;
+    if (pk.first != 69.0 || pk.second != 202) { std::fprintf(stderr, "wrong answer (%g, %zu)\n", pk.first, pk.second); return 1; }
+
+    // (2) peaks only
+    std::vector<uint64_t> idx(shifts.size());
+    std::vector<double> val(shifts.size());
+    caf_peak p{};
+    auto peaks_only = [&] {
+        check(caf_surface_c128(default_ctx(), reinterpret_cast<const double *>(needle.data()), reinterpret_cast<const double *>(hay.data()), n,
+                               shifts.data(), shifts.size(), 48000, nullptr, idx.data(), val.data(), &p), "caf_surface_c128");
+    };
+    for (int i = 0; i < 10; ++i) peaks_only();
+    t0 = now_s();
+    const int po = 500;
+    for (int i = 0; i < po; ++i) peaks_only();
+    const double us_peaks = (now_s() - t0) / po * 1e6;
+    if (p.freq != 69.0 || p.idx != 202) { std::fprintf(stderr, "wrong answer (peaks only)\n"); return 1; }
+
+    // (3) B pairs per call: pair b = the chirp_0 pair with the haystack delayed by (b % 64) more samples -> tau = 202 + b % 64
+    std::vector<Complex64> nds(B * n), hss(B * n, Complex64(0.0, 0.0));
+    for (std::size_t b = 0; b < B; ++b) {
+        const std::size_t d = b % 64;
+        std::copy(needle.begin(), needle.end(), nds.begin() + b * n);
+        std::copy(hay.begin(), hay.end() - d, hss.begin() + b * n + d);
+    }
+    const int ndev = caf_device_count();
+    std::vector<int> devices;
+    for (int d = 0; d < ndev; ++d) devices.push_back(d);
+    // the in-library RCCL join if librccl can be loaded (the library dlopen()s it), else the host join
+    std::unique_ptr<CafHipBatch> bp;
+    const char *join = "rccl";
+    try {
+        bp.reset(new CafHipBatch(devices, n, shifts, 48000, /*rccl=*/true));
+    } catch (const std::runtime_error &e) {
+        std::fprintf(stderr, "RCCL join not available (%s): joining the peaks on the host\n", e.what());
+        join = "host";
+        bp.reset(new CafHipBatch(devices, n, shifts, 48000, /*rccl=*/false));
+    }
+    CafHipBatch &batch = *bp;
+    auto got = batch.upload(nds, hss);  // allocations + first upload
+    t0 = now_s();
+    for (int i = 0; i < calls; ++i) got = batch.upload(nds, hss);
+    const double ms_upload = (now_s() - t0) / calls * 1e3;
+    for (int i = 0; i < 3; ++i) got = batch.find_peaks();
+    t0 = now_s();
+    for (int i = 0; i < calls; ++i) got = batch.find_peaks();
+    const double ms_resident = (now_s() - t0) / calls * 1e3;
+    for (std::size_t b = 0; b < B; ++b)
+        if (got[b].second != 202 + b % 64 || (got[b].first != 69.0 && got[b].first != 69.5)) {
+            std::fprintf(stderr, "pair %zu: wrong answer (%g, %zu)\n", b, got[b].first, got[b].second);
+            return 1;
+        }
+    std::printf("{\"shape\": \"400x8192 complex128, chirp_0 pair\", \"gpus\": %d, \"peak_join\": \"%s\", \"literal_loop_ms_per_surface\": %.3f, "
+                "\"peaks_only_us_per_surface\": %.1f, \"batch\": %zu, \"batch_with_upload_ms_per_call\": %.3f, "
+                "\"batch_with_upload_surfaces_per_s\": %.0f, \"batch_resident_ms_per_call\": %.3f, \"batch_resident_surfaces_per_s\": %.0f, "
+                "\"published_rust_threadpool_ms_per_surface_R9_3900X\": 28}\n",
+                ndev, join, ms_literal, us_peaks, B, ms_upload, B / ms_upload * 1e3, ms_resident, B / ms_resident * 1e3);
+    return 0;
+}
