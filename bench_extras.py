@@ -132,6 +132,26 @@ def host_api_times(reps=200):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def compiled_host_bench(batch=256, calls=10):
+    """examples/caf_bench.cpp (built as tests/cpp/caf_bench): the reference's bench loop (benches/caf_bench.rs:150-168) from a
+    COMPILED host over the C ABI -- the literal one-call-per-iteration loop, the peaks-only call, and the loop as one
+    caf_multi_surface_run_batch call per `batch` pairs with the in-library RCCL join.  A child process without Python; it checks
+    its own answers.  Reported, never `value` (its batched figure from HBM is the same measurement as `value`, one level down)."""
+    exe = ROOT / "tests" / "cpp" / "caf_bench"
+    try:
+        if not exe.exists():
+            subprocess.run(["make", "-C", str(exe.parent), "caf_bench"], check=True, capture_output=True, timeout=300)
+        r = subprocess.run([str(exe), str(ROOT / "tests" / "golden" / "data"), str(batch), str(calls)], capture_output=True, text=True,
+                           timeout=300, cwd=str(ROOT))
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout).strip()[-300:]}
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out["how"] = "tests/cpp/caf_bench (C++, child process, system HIP + librccl): examples/caf_bench.cpp"
+        return out
+    except Exception as e:  # reported, never fatal for the bench line
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def stream_run(plan, nd, hs, lags, total, nslots, batch, split, three_kernels=False, native=True, passes=5, memcpy_nodes=False):
     """`total` surfaces through a caf_stream.  native: the whole loop is one caf_stream_run call (fill the
     slot's pinned buffers, replay its graph, retire the oldest slot -- in C++, as a compiled host would);
@@ -567,6 +587,7 @@ def n1_extras(args, eng, torch, dev, local_rank, freqs, K, extra):
     # (a child process, timed from C: before the in-process legs below, whose 13 GB of slab allocations and frees would otherwise
     #  sit between it and the streaming measurements it has always followed)
     extra["host_api"] = host_api_times()
+    extra["compiled_host_bench"] = compiled_host_bench(batch=args.batch)
     try:
         extra["in_process_multi"] = in_process_config3([local_rank], steps=10, warmup=2, forms=("host_join", "rccl_join"))
         extra["in_process_multi"]["two_contexts_same_gpu"] = in_process_config3(
