@@ -455,3 +455,26 @@ def test_multi_surface_on_device_default_and_device_kept(eng):
         ms.run(x, y, want_surface=True)
     ms.close()
     assert torch.cuda.current_device() == before
+
+
+def test_multi_batch_kat_pairs_c64(eng, oracle, coracle):
+    """The reference's ten pairs as one complex64 batch on the bench grid (BASELINE configs[2] behind the batch call), two
+    workers: tau exact for every pair, the row the f64 oracle picks or its neighbour (chirp_0's two best rows differ by 6.8e-6
+    of the maximum, SURVEY.md section 7: below complex64's reach), peak values within 1e-3 of the maximum."""
+    import caf_cookoff_amd as caf
+    fr = caf.bench_shifts()
+    pairs = [_pair(oracle, k) for k in range(10)]
+    nd, hs = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    ms = caf.MultiSurface([0, 0], 4096, fr, FS, dtype="c64", surface_on_device=True)
+    ridx, rval, peaks = ms.run_batch(nd.astype(np.complex64), hs.astype(np.complex64))
+    exact = 0
+    for k in range(10):
+        _, oidx, oval = coracle.caf_surface(nd[k], hs[k], fr, FS, want_surface=False, hoist=True, nthreads=4)
+        of, oi = coracle.find_peak(fr, oidx, oval)
+        assert int(peaks[k]["idx"]) == oi, f"pair {k}"
+        assert abs(float(peaks[k]["freq"]) - of) <= 0.5 + 1e-9, f"pair {k}"
+        assert abs(float(peaks[k]["val"]) - oval.max()) <= TOL32 * oval.max()
+        assert np.max(np.abs(rval[k].astype(np.float64) - oval)) <= TOL32 * oval.max()
+        exact += float(peaks[k]["freq"]) == of
+    assert exact >= 9          # (all ten on every box so far; chirp_0 is the one that may move to the neighbouring row)
+    ms.close()
