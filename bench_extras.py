@@ -220,20 +220,26 @@ def stream_case(eng, torch, freqs, total=1000):
     find_peak} from three on; the host reads completion from a pinned sequence word.  Reported forms:
       single_2slots / _3slots / _4slots   one surface per graph replay, native loop (caf_stream_run)
       split4_2slots                   four independent single-surface chains per replay
-      batched4_2slots / batched8_4slots   one batched chain of four / eight surfaces per replay (coarser granularity:
-                                      60-62 k surfaces/s with eight per replay and four slots, tools/stream_batch_sweep.py)
-      batched8_4slots_memcpy_nodes / batched1_2slots_memcpy_nodes
+      batched4_2slots / batched8_4slots / batched20_2slots / batched32_2slots
+                                      one batched chain of four / eight / 20 / 32 surfaces per replay
+      batched20_2slots_memcpy_nodes / batched8_4slots_memcpy_nodes / batched1_2slots_memcpy_nodes
                                       BASELINE configs[4] TO THE LETTER: the inputs cross PCIe as hipMemcpyAsync (copy-engine) nodes of
                                       the slot's graph into device buffers, the results come back as hipMemcpyAsync nodes
-                                      (CAF_STREAM_MEMCPY_NODES); eight surfaces per replay on four slots, and the plain
-                                      double-buffered form: one surface per replay on two slots
+                                      (CAF_STREAM_MEMCPY_NODES); the fixed form, eight per replay on four slots, and one
+                                      surface per replay on two slots
       single_2slots_three_kernels     round-2a form {spectrum, rows, find_peak} as three nodes (for comparison)
       single_2slots_python_loop       submit / wait driven from Python, step by step (for comparison)
-    `value` = the FIXED form batched8_4slots (eight surfaces per graph replay, four slots): the fastest form AND the one
-    whose rate does not depend on how the runtime happens to map the slot streams onto its hardware queues
-    (tools/stream_form_stability.py, profiles/r03_stream/form_stability.txt: 55.4-58.6 k surfaces/s over six
-    creations, against 38.7-55.0 k for single_4slots, whose single-surface chains serialise when two slots share a
-    queue); the other forms are reported beside it, never selected from."""
+    `value` = the FIXED form batched20_2slots (20 surfaces per graph replay, two slots: the plain double buffer of the config
+    text; 1000 surfaces = exactly 50 replays, no ragged last one), since round 5.  Why larger replays on two slots instead of
+    rounds 3-4's eight per replay on four: 8 surfaces are 3 200 rows = 6.25 rounds of the 512 persistent row workgroups (a seventh,
+    quarter-full round per launch: 141 us against 119 us at the batched rate), 20 are 16.7; and the row launch of a replay of 16
+    surfaces or more leaves 32 workgroup slots free, so that the other slot's staging + spectrum launch runs beside it instead
+    of in its tail (row workgroups hold every register of the CUs they fill; HISTORY.md R5.6: 32 per replay on two slots 53 k
+    surfaces/s without the free slots, 64-67 k with them).  tools/stream_1000.py, profiles/r05_stream/stream_1000.txt (1000
+    surfaces, median of 9 passes, each form visited twice): 20 x 2 slots 64.5-64.7 k, 25 x 2 64.0-64.3 k, 32 x 2 62.1-62.2 k (its
+    last replay is three quarters padding), 8 x 4 61.6-62.5 k; for long streams 32 x 2 is the flattest form
+    (tools/stream_form_stability.py, profiles/r05_stream/form_stability.txt: 64.2-64.6 k over six creations against 61.5-62.8 k
+    for 8 x 4 and 47-58 k for one surface per replay on four slots).  The other forms are reported beside it, never selected from."""
     from caf_cookoff_amd.synth import make_batch
     plan = eng.plan(N_SAMP, freqs, FS)
     nd, hs, lags, _ = make_batch(64, N_SAMP, FS, seed0=5000)
@@ -243,6 +249,9 @@ def stream_case(eng, torch, freqs, total=1000):
             ("single_4slots", 4, 1, False, False, True, False),
             ("split4_2slots", 2, 4, True, False, True, False), ("batched4_2slots", 2, 4, False, False, True, False),
             ("batched8_4slots", 4, 8, False, False, True, False),
+            ("batched20_2slots", 2, 20, False, False, True, False),
+            ("batched32_2slots", 2, 32, False, False, True, False),
+            ("batched20_2slots_memcpy_nodes", 2, 20, False, False, True, True),
             ("batched8_4slots_memcpy_nodes", 4, 8, False, False, True, True),
             ("batched1_2slots_memcpy_nodes", 2, 1, False, False, True, True),
             ("single_2slots_three_kernels", 2, 1, False, True, True, False),
@@ -254,16 +263,16 @@ def stream_case(eng, torch, freqs, total=1000):
             forms[name].update(getattr(stream_run, "last_spread", {}))
     plan.close()
     abytes = algorithmic_bytes(1, 400, N_SAMP, "c128")
-    best = "batched8_4slots"
+    best = "batched20_2slots"
     return {"workload": f"{total} back-to-back 400x8192 complex128 surfaces from host memory, hipGraph replay per slot, "
                         "stage-in of inputs and stage-out of peaks included, surfaces left on the device (BASELINE configs[4]); "
                         "`value`: the kernels read and write mapped pinned host memory in place; the literal form of the config text "
-                        "(hipMemcpyAsync nodes both ways) is reported beside it as forms.batched8_4slots_memcpy_nodes / "
-                        "batched1_2slots_memcpy_nodes and as `memcpy_nodes_value`",
+                        "(hipMemcpyAsync nodes both ways) is reported beside it as forms.batched20_2slots_memcpy_nodes / "
+                        "batched8_4slots_memcpy_nodes / batched1_2slots_memcpy_nodes and as `memcpy_nodes_value`",
             "value": forms[best]["value"], "unit": "surfaces/s", "form": best, "forms": forms,
             "value_is": f"median of {forms[best].get('passes')} passes over the {total} pairs (one more pass before them warms up)",
             "value_min": forms[best].get("value_min"), "value_max": forms[best].get("value_max"),
-            "memcpy_nodes_value": forms["batched8_4slots_memcpy_nodes"]["value"],
+            "memcpy_nodes_value": forms["batched20_2slots_memcpy_nodes"]["value"],
             "algorithmic_bytes_per_surface": abytes, "frac": abytes * forms[best]["value"] / 1e9 / HBM_PEAK_GBS}
 
 
@@ -436,8 +445,8 @@ def multi_gpu_extras(args, eng, torch, dist, dev, rank, world, rehearse, freqs):
     mine = (first + stride * np.arange(items)) % 64      # pair k of the run is pool entry k % 64
     a, b, want = nd[mine], hs[mine], np.asarray(lags)[mine]
     plan = eng.plan(N_SAMP, freqs, FS)
-    st = caf.Stream(plan, batch=8, nslots=4, want_surface=True)   # the fixed form of extra.configs4_stream
-    st.run(a[:32], b[:32])   # warm the graphs
+    st = caf.Stream(plan, batch=20, nslots=2, want_surface=True)   # the fixed form of extra.configs4_stream
+    st.run(a[:40], b[:40])   # warm the graphs
     best = None
     for rep in range(2):
         sync_all()
@@ -450,7 +459,7 @@ def multi_gpu_extras(args, eng, torch, dist, dev, rank, world, rehearse, freqs):
     plan.close()
     out["configs4_stream_surface_parallel"] = {
         "workload": f"{total} back-to-back 400x8192 complex128 surfaces from host memory, whole surfaces round-robin over "
-                    f"{world} ranks ({items} on rank 0), one caf_stream (eight surfaces per replay, 4 slots) per rank, no collective on the data path "
+                    f"{world} ranks ({items} on rank 0), one caf_stream (20 surfaces per replay, 2 slots) per rank, no collective on the data path "
                     "(BASELINE configs[4], surface-parallel decomposition)",
         "value": total / best, "unit": "surfaces/s", "elapsed_ms_max_over_ranks": best * 1e3,
         "tau_correct": f"{okc}/{total}"}

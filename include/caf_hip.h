@@ -214,12 +214,12 @@ int caf_surface_view(caf_ctx *ctx, int dtype, const void *surface, size_t rows, 
  * pinned results through their device mappings (the haystack is read in place, the needle is
  * staged into device memory by the spectrum launch, find_peak writes the row peaks and the
  * caf_peak records out) -- no copy-engine nodes.  While slot k computes, the caller fills slot
- * k+1's pinned buffers and submits it: its input transfer overlaps slot k's kernels.  Three or
- * four slots sustain the most single-surface replays per second on MI355X (HISTORY.md section 9; the
- * slot streams are probed at creation so that they sit on separate hardware queues), but that rate
- * depends on how the runtime arbitrates the slot streams' hardware queues; batch = 8 with four slots
- * is the fastest form measured and the one that keeps its rate from creation to creation
- * (profiles/r03_stream/form_stability.txt).  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
+ * k+1's pinned buffers and submits it: its input transfer overlaps slot k's kernels.  The fastest form measured on MI355X, and
+ * the one that keeps its rate from creation to creation, is batch = 20 ... 32 on two slots (n = 4096, 400 rows: 16 to 25 rounds of the
+ * persistent row workgroups per replay instead of 6.25 with eight surfaces; the row launch of a replay of 16 surfaces or more leaves 32 workgroup slots free so
+ * that the other slot's staging + spectrum launch runs beside it: profiles/r05_stream/form_stability.txt);
+ * single-surface replays depend on how the runtime arbitrates the slot streams' hardware queues (the slot streams are probed at
+ * creation so that they sit on separate ones; profiles/r03_stream/form_stability.txt).  Surfaces stay on the device (d_surface of the slot, NULL if want_surface == 0);
  * only (tau, f) + per-row peaks come back, as SURVEY.md section 8d prescribes.
  * Plans whose row kernel keeps its intermediate data on-chip ("fused4096", "chain", "small") give
  * every slot private device state, so slots execute concurrently.  Plans on the

@@ -20,7 +20,7 @@ plan = eng.plan(4096, caf.bench_shifts(), 48000)
 nd16, hs16, lags16, _ = make_batch(16, 4096, 48000, seed0=5000)
 reps = (count + 15) // 16
 nd, hs = np.tile(nd16, (reps, 1))[:count], np.tile(hs16, (reps, 1))[:count]
-forms = [(1, 2), (1, 3), (1, 4), (8, 2), (8, 3), (8, 4), (16, 2), (32, 2), (64, 2)]
+forms = [(1, 4), (8, 4), (16, 4), (24, 2), (32, 2), (32, 3), (48, 2), (64, 2)]
 res = {f: [] for f in forms}
 for it in range(ncreate):
     for b, s in forms:
