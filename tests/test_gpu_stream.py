@@ -349,7 +349,7 @@ def test_small_path_streaming_slots(n, dtype, split, eng, oracle):
 
 
 @pytest.mark.parametrize("dtype,n,batch,nslots", [("c128", 4096, 8, 4), ("c128", 4096, 1, 2), ("c64", 4096, 3, 2), ("c64", 2048, 2, 2),
-                                                  ("c128", 64, 5, 3)])
+                                                  ("c128", 64, 5, 3), ("c128", 4096, 20, 2), ("c64", 4096, 32, 2), ("c128", 4096, 16, 3)])
 def test_stream_memcpy_nodes_form_equals_mapped_form(dtype, n, batch, nslots, eng, oracle):
     """CAF_STREAM_MEMCPY_NODES (BASELINE configs[4] to the letter: hipMemcpyAsync nodes carry the inputs in and the results out)
     returns the same bits as the default form (kernels read / write the mapped pinned buffers) for the same batched chain, and
@@ -372,4 +372,18 @@ def test_stream_memcpy_nodes_form_equals_mapped_form(dtype, n, batch, nslots, en
         assert p0.tobytes() == p1.tobytes() and np.array_equal(v0, v1)
     else:
         assert np.array_equal(p0["idx"], p1["idx"]) and np.array_equal(p0["row"], p1["row"]) and np.allclose(v0, v1, rtol=1e-12, atol=0)
+    if batch >= 16:
+        # replays of 16 surfaces or more launch their rows on 32 workgroup slots fewer (api/stream.inc): the same bits as the
+        # device-pointer batch of the same pairs on the full grid, row records and peaks
+        import torch
+        tdt = torch.float64 if dtype == "c128" else torch.float32
+        dn, dh = torch.from_numpy(nd).cuda(), torch.from_numpy(hs).cuda()
+        di = torch.empty((count, len(fr)), dtype=torch.int64, device="cuda")
+        dv = torch.empty((count, len(fr)), dtype=tdt, device="cuda")
+        dp = torch.empty((count, 4), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        plan.surface_dev(dn.data_ptr(), dh.data_ptr(), count, None, di.data_ptr(), dv.data_ptr(), dp.data_ptr())
+        eng.synchronize()
+        assert np.array_equal(i0.astype(np.int64), di.cpu().numpy()) and np.array_equal(v0, dv.cpu().numpy())
+        assert p0.tobytes() == dp.cpu().numpy().tobytes()
     plan.close()
