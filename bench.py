@@ -5,8 +5,13 @@
 
 N > 1 without a torchrun environment: this process (before it imports torch or touches HIP)
 starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>`
-as a CHILD process, relays rank 0's JSON line and exits with the child's status.  Launched by
-torchrun directly (RANK/WORLD_SIZE set) it runs as one rank.
+as a CHILD process and relays rank 0's JSON line.  If that tree ends non-zero or without a line,
+a SECOND fresh child runs the same headline through the one-process path (`--in-process`: no
+torchrun, no rendezvous, no torch.distributed) and its line is relayed with
+`config.fallback_from` = {path, rc, stderr_tail} of the path that failed.  Launched by torchrun
+directly (RANK/WORLD_SIZE set) it runs as one rank; there rank 0 starts the same fallback child
+itself when a phase BEFORE the headline fails or overruns (the other ranks wait for it, so the
+launcher does not end rank 0 early).  No process is ever re-exec'ed or restarted.
 
 A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 256)
 distinct (needle, haystack) pairs per GPU, each a 400 x 8192 complex128 filterbank CAF
@@ -31,20 +36,27 @@ warm-up, the correctness gate, the timed region and everything after it; a rank 
 phase writes one stderr line (rank, device, phase) and leaves with status 3, without a result line
 unless the headline had been measured before (then rank 0 prints it with `extra.error`).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with
+Rank 0 prints ONE JSON line on stdout -- the LAST and only stdout line, at most 4 096 bytes
+(bench_common.compact_line / LINE_LIMIT) -- with the contract's keys and
+  `config`       the workload, who sat where (`rank_devices`), the collective backend and world
+                 size (`rccl_world`) and every rank's row-kernel time (`rank_kernel_ms`, + spread
+                 and a flag above 10 %);
   `roofline`     dominant kernel, HBM bound, algorithmic bytes / HIP-event kernel time; for the
                  complex128 headline also `secondary` = the FP64-VALU issue ceiling of the
                  shipped instruction stream, measured live with the math-only ablation of the
                  measurement library (no LDS traffic, no loads, no stores);
   `cpu_baseline` the C restatement of caf_rust timed on this box's host cores (model and
-                 core counts stated);
-  `extra`        (N = 1) the other BASELINE configs measured in the same process after the
-                 headline (bench_extras.n1_extras): configs[2] complex64, configs[3] 4096 x 65536
-                 complex64 (whole surface and the 512-row shard one of 8 GPUs gets), configs[4]
-                 streaming, the in-process multi-device calls and `host_api`, the literal drop-in
-                 calls timed from C next to the PCIe floor;
-                 (N > 1) `configs3_c64_sharded` and `configs4_stream_surface_parallel`: the two
-                 multi-GPU decompositions of the other configs (bench_extras.multi_gpu_extras).
+                 core count stated);
+  `extra`        one scalar pair per other BASELINE config: (N = 1) configs[2] complex64,
+                 configs[3] 4096 x 65536 complex64 (whole surface and the 512-row shard one of 8
+                 GPUs gets), configs[4] streaming in its ONE fixed form and its ONE literal
+                 hipMemcpyAsync-node form, `host_api` / `compiled_host_bench` (the drop-in calls
+                 timed from C / C++), `in_process_headline`; (N > 1) `configs3_c64_sharded` and
+                 `configs4_stream_surface_parallel`; and `detail_file`.
+The FULL record (every figure, how it was taken, the per-form tables) goes to
+bench_detail.json next to this file and, as one line, to stderr.  `--sweeps` adds the
+comparison forms (other streaming forms, both joins, `with_upload`, two contexts on one GPU) to
+the full record; they never enter the line.
 """
 from __future__ import annotations
 
@@ -57,13 +69,19 @@ import time
 from datetime import timedelta
 from pathlib import Path
 
-from bench_common import (EXTRAS_LIMIT_S, FS, HBM_ACHIEVABLE_GBS, HBM_PEAK_GBS, N_SAMP, ROOT, Case, PhaseWatchdog,  # noqa: F401
-                          algorithmic_bytes, block_stats, emit_line, guard_stdout, kernel_source_hash, profiled_traffic,
-                          roofline_entry, secondary_entry, traffic_fields, under_rocprofiler)
+from bench_common import (EXTRAS_LIMIT_S, FS, HBM_ACHIEVABLE_GBS, HBM_PEAK_GBS, LINE_LIMIT, N_SAMP, ROOT, Case, PhaseWatchdog,  # noqa: F401
+                          algorithmic_bytes, block_stats, compact_line, emit_line, emit_result, guard_stdout, kernel_source_hash,
+                          profiled_traffic, roofline_entry, secondary_entry, traffic_fields, under_rocprofiler)
 from bench_extras import (cpu_baseline, cpu_baseline_config3, host_api_times, in_process_config3, in_process_headline,  # noqa: F401
                           issue_ceiling, multi_gpu_extras, multi_stream_case, n1_extras, stream_case, stream_run)
 
-RENDEZVOUS_TIMEOUT_S = 120     # init_process_group and every collective of the process group
+# init_process_group and every collective of the process group.  LONGER than every phase limit of the watchdog that can
+# apply to a collective run (bench_common.PhaseWatchdog.LIMITS: <= 240 s): the phase watchdog must be the one that ends a hung
+# rank -- it names rank, device and phase and, before the headline exists, lets rank 0 fall back to the one-process path --
+# not torch's own NCCL watchdog, which aborts the process without either.
+RENDEZVOUS_TIMEOUT_S = 360
+LAUNCH_TIMEOUT_S = 480         # self_launch: the whole torchrun tree (a healthy N = 8 run: import + ~1 minute)
+FALLBACK_TIMEOUT_S = 360       # the one-process fallback child
 
 
 def parse_args(argv=None):
@@ -104,6 +122,13 @@ def parse_args(argv=None):
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="G",
                     help="ONE GPU, no collective: launch exactly what rank 0 of a G-GPU run launches per step (batch*G surfaces x "
                          "rows [0, F/G)); for profiling the per-rank launch shapes (profiles/r04_rankshape_*), never a scaling figure")
+    ap.add_argument("--sweeps", action="store_true",
+                    help="also measure the comparison forms (the other streaming forms, both peak joins, the same call with the "
+                         "upload inside, two contexts on one GPU, the in-process configs[3] calls): they go into bench_detail.json, "
+                         "never into the line")
+    ap.add_argument("--no-fallback", action="store_true",
+                    help="N>1: a failure before the headline ends the run (non-zero, no line) instead of starting the one-process "
+                         "path as a fresh child")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no GPU work: launch + rendezvous + peak reduction + JSON relay on fabricated shard peaks "
                          "(gloo); what the CPU test suite runs")
@@ -117,11 +142,112 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+_RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+             "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+             "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING",
+             "TORCHELASTIC_ERROR_FILE", "CAF_BENCH_UNDER_LAUNCHER")
+
+
+def last_json_line(text: str):
+    """the last stdout line that is a JSON object, or None"""
+    import json
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def run_child(cmd, env, limit_s):
+    """One child process tree in its own session: stdout captured (it carries at most the one line), stderr passed through
+    and its tail kept.  Past `limit_s` the tree's process GROUP -- the one started here, nothing found by name -- is ended.
+    -> (rc | None when it had to be ended, stdout text, stderr tail)."""
+    import collections
+    import signal
+    import threading
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+    tail = collections.deque(maxlen=40)
+    own = collections.deque(maxlen=6)   # bench.py's own one-line diagnostics say more than a launcher's failure summary
+    out = []
+
+    def pump_err():
+        for raw in iter(proc.stderr.readline, b""):
+            os.write(2, raw)
+            if raw.startswith(b"bench.py detail: "):
+                continue
+            text = raw.decode("utf-8", "replace")
+            (own if "bench.py" in text and "did not finish" in text or text.startswith("bench.py:") else tail).append(text)
+
+    def pump_out():
+        out.append(proc.stdout.read())
+
+    threads = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for t in threads:
+        t.start()
+    rc = None
+    try:
+        rc = proc.wait(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
+            try:
+                os.killpg(proc.pid, sig)   # (start_new_session: the group id is the child's pid)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        tail.append(f"bench.py: the child did not finish within {limit_s:g} s and was ended\n")
+    for t in threads:
+        t.join(timeout=5)
+    return rc, (out[0] if out else b"").decode("utf-8", "replace"), ("".join(own) or "".join(tail))[-1500:]
+
+
+def in_process_fallback_cmd(args):
+    """`bench.py --gpus N --in-process` with this run's measurement flags"""
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", str(args.gpus), "--in-process", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--batch", str(args.batch), "--dtype", args.dtype, "--blocks", str(args.blocks),
+           "--cpu-seconds", str(args.cpu_seconds), "--cpu-threads", str(args.cpu_threads)]
+    for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-check", args.no_check), ("--no-extra", args.no_extra),
+                     ("--plumbing-only", args.plumbing_only), ("--sweeps", args.sweeps)):
+        if on:
+            cmd.append(flag)
+    if args.in_process_devices:
+        cmd += ["--in-process-devices", args.in_process_devices]
+    return cmd
+
+
+def run_in_process_fallback(args, failed):
+    """Start the one-process path as a FRESH child (clean of every rank variable) and relay its line with
+    config.fallback_from = `failed` ({path, rc, stderr_tail} of what did not produce a line).  -> True if a line was printed."""
+    env = {k: v for k, v in os.environ.items() if k not in _RANK_ENV}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"bench.py: the {failed.get('path')} path gave no result (rc {failed.get('rc')}); running the same headline through the "
+          "one-process path (--in-process) as a fresh child", file=sys.stderr)
+    rc, out, err = run_child(in_process_fallback_cmd(args), env, FALLBACK_TIMEOUT_S)
+    line = last_json_line(out)
+    if line is None or (line.get("value") is None and not line.get("plumbing_only")):
+        print(f"bench.py: the one-process fallback gave no result either (rc {rc})", file=sys.stderr)
+        return False
+    line.setdefault("config", {})["fallback_from"] = {"path": failed.get("path"), "rc": failed.get("rc"),
+                                                      "stderr_tail": str(failed.get("stderr_tail", ""))[-300:]}
+    if rc != 0:
+        line["config"]["child_rc"] = rc
+    from bench_common import shrink_to_limit
+    emit_line(shrink_to_limit(line))
+    return True
+
+
 def self_launch(args) -> int:
-    """--gpus N > 1 outside torchrun: run the N ranks as a child process tree.  Nothing in THIS
-    process has imported torch or touched HIP (a process that initialised the GPU must never be
-    replaced or fork GPU users on this pool) -- unless a profiler's preloaded tool library did it
-    for us: then the launch is refused."""
+    """--gpus N > 1 outside torchrun: run the N ranks as a child process tree.  Nothing in THIS process has imported torch or
+    touched HIP (a process that initialised the GPU must never be replaced) -- unless a profiler's preloaded tool library did
+    it for us: then the launch is refused.  The tree's stdout is captured; its line is relayed when it holds a measured
+    headline (a later phase may have failed: the line then says so under extra.error and config.child_rc).  Otherwise the
+    one-process path runs as a second fresh child (run_in_process_fallback).  Exit status 0 only if a line was printed."""
     if under_rocprofiler():
         print("bench.py: --gpus N > 1 under rocprofv3 would start torchrun from a process whose GPU the profiler's preload has "
               "already initialised; profile a rank's launch shape with --emulate-rank-of N, or the one-process path with "
@@ -133,22 +259,84 @@ def self_launch(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=env).returncode  # stdout is inherited: rank 0's JSON line is ours
+    env["CAF_BENCH_UNDER_LAUNCHER"] = "1"   # the ranks leave the fallback to this process (it holds no GPU and outlives them)
+    rc, out, err = run_child(cmd, env, float(os.environ.get("CAF_BENCH_LAUNCH_TIMEOUT_S", LAUNCH_TIMEOUT_S)))
+    line = last_json_line(out)
+    if line is not None and (line.get("value") is not None or (line.get("plumbing_only") and rc == 0)):
+        if rc != 0:
+            line.setdefault("config", {})["child_rc"] = rc
+        from bench_common import shrink_to_limit
+        emit_line(shrink_to_limit(line))
+        return 0
+    if args.no_fallback:
+        return rc if rc else 3
+    return 0 if run_in_process_fallback(args, {"path": "torchrun", "rc": rc, "stderr_tail": err}) else (rc if rc else 3)
+
+
+class RankFallback:
+    """Launched by a torchrun that is NOT ours (RANK / WORLD_SIZE set, no CAF_BENCH_UNDER_LAUNCHER): when a phase before the
+    headline fails or overruns, rank 0 starts the one-process path as a fresh child and relays its line; every other rank
+    waits for rank 0's verdict (a file under /tmp keyed by the launcher's pid and port) instead of leaving at once -- the
+    launcher ends the remaining ranks as soon as one exits non-zero, and rank 0 needs about a minute.  Every rank then leaves
+    with rank 0's status.  Called from the watchdog thread (a main thread stuck in a collective cannot be unwound) or from
+    the main thread's exception handler; whoever comes first runs it, once."""
+
+    WAIT_S = 420.0
+
+    def __init__(self, args, rank, world):
+        import threading
+        self.args, self.rank, self.world = args, rank, world
+        self.enabled = (world > 1 and not args.no_fallback and os.environ.get("CAF_BENCH_UNDER_LAUNCHER") != "1"
+                        and not args.in_process and not args.emulate_rank_of)
+        self.flag = Path("/tmp") / f"caf_bench_fallback_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
+        self._once = threading.Lock()
+        if self.enabled and rank == 0:
+            try:
+                self.flag.unlink()
+            except OSError:
+                pass
+
+    def run(self, reason: str) -> int:
+        """-> the status this rank should leave with"""
+        if not self.enabled:
+            return 3
+        if not self._once.acquire(blocking=False):
+            time.sleep(self.WAIT_S)   # the other thread of this process is running it and will end the process
+            return 3
+        if self.rank == 0:
+            time.sleep(float(os.environ.get("CAF_BENCH_FALLBACK_SETTLE_S", "3")))   # let the other ranks reach their own limits
+            ok = run_in_process_fallback(self.args, {"path": "torchrun (external launcher)", "rc": None, "stderr_tail": reason})
+            try:
+                self.flag.write_text("ok" if ok else "fail")
+            except OSError:
+                pass
+            return 0 if ok else 3
+        t_end = time.monotonic() + self.WAIT_S
+        os.write(2, f"bench.py: rank {self.rank}: {reason}; waiting for rank 0's one-process fallback\n".encode())
+        while time.monotonic() < t_end:
+            try:
+                return 0 if self.flag.read_text().strip() == "ok" else 3
+            except OSError:
+                time.sleep(0.5)
+        return 3
 
 
 # ------------------------------------------------------------------------------ the line --
 LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "extra")
+# keys of the full record's `roofline` (bench_detail.json); the line carries bench_common._ROOFLINE_LINE_KEYS of them
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_is", "traffic_source", "kernel",
                  "kernel_ms", "launches_timed", "algorithmic_bytes_per_launch", "frac_of_achievable_6.29TBs", "whole_step_frac")
-MULTI_EXTRA_KEYS = ("rank_kernel_ms", "rccl_world", "headline_blocks", "configs3_c64_sharded", "configs4_stream_surface_parallel")
-KERNEL_SPREAD_FLAG = 0.10   # extra.rank_kernel_ms_flag when (max - min) / min of the ranks' row-kernel times exceeds this
+MULTI_EXTRA_KEYS = ("headline_blocks", "configs3_c64_sharded", "configs4_stream_surface_parallel")
+# who sat where and that every rank worked: in `config`, which the driver's record keeps whole (`extra` it reduces to a key list)
+RANK_EVIDENCE_KEYS = ("rank_devices", "rccl_world", "rank_kernel_ms", "rank_kernel_ms_spread", "rank_kernel_ms_flag")
+KERNEL_SPREAD_FLAG = 0.10   # config.rank_kernel_ms_flag when (max - min) / min of the ranks' row-kernel times exceeds this
 
 
 def assemble_line(args, *, F, n_samp, world, n_gpus_seen, nsurf, rows, K, el, kern_ms, launches, kernel_name, kernel_path,
-                  devname, cu, ndev, peak_exchange, rank_devices=None):
-    """The ONE place the bench line is put together: the measured run at any N, the in-process run and the --plumbing-only
-    rehearsal (fabricated measurements) go through it, so that every line carries the same keys (tests/test_bench_launch.py
+                  devname, cu, ndev, peak_exchange, rank_devices=None, rccl_world=None, rank_kernel_ms=None):
+    """The ONE place the bench record is put together: the measured run at any N, the in-process run and the --plumbing-only
+    rehearsal (fabricated measurements) go through it, so that every record carries the same keys (tests/test_bench_launch.py
     compares them).  `cpu_baseline` and `extra` are filled in by the caller after the timed region; both keys always exist."""
     value = nsurf * K / el if el and el > 0 else None
     abytes = algorithmic_bytes(nsurf, rows, n_samp, args.dtype)
@@ -163,49 +351,103 @@ def assemble_line(args, *, F, n_samp, world, n_gpus_seen, nsurf, rows, K, el, ke
                  "frac_of_achievable_6.29TBs": roof["achieved"] / HBM_ACHIEVABLE_GBS if roof["achieved"] else None,
                  "whole_step_frac": (abytes * K / el / 1e9) / HBM_PEAK_GBS if el and el > 0 else None})
     cfg_idx = 3 if n_samp == 32768 else 1 if args.dtype == "c128" else 2
+    config = {"workload": f"{F}x{2 * n_samp} {'complex128' if args.dtype == 'c128' else 'complex64'} "
+                          f"filterbank CAF (BASELINE configs[{cfg_idx}]), n={n_samp}, fs=48000",
+              "surfaces_per_step": nsurf, "batch_per_gpu": args.batch,
+              "rows_per_gpu": rows, "parallelism": f"doppler-row-shard x{world}" if world > 1 else "single",
+              "peak_exchange": peak_exchange,
+              "kernel_path": kernel_path, "device": devname, "cus": cu,
+              "devices_visible_per_rank": ndev,
+              "rank_devices": rank_devices if rank_devices is not None else [{"rank": 0, "device": 0, "visible": ndev}],
+              "rccl_world": rccl_world,
+              "kernel_source_hash": kernel_source_hash(kernel_name)}
+    config.update(kernel_spread(rank_kernel_ms if rank_kernel_ms is not None else [kern_ms]))
     return {
         "metric": "CAF surfaces/sec (400 freqs x 8192 samp, c128)"
                   if (F == 400 and args.dtype == "c128" and n_samp == N_SAMP)
                   else f"CAF surfaces/sec ({F} freqs x {2 * n_samp} samp, {args.dtype})",
         "value": value, "unit": "surfaces/s", "n_gpus": n_gpus_seen, "steps": K, "warmup": args.warmup,
-        "ms_per_step": el / K * 1e3 if K else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": el / K * 1e3 if K and el else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64" if args.dtype == "c128" else "f32", "data": "synthetic",
-        "config": {"workload": f"{F}x{2 * n_samp} {'complex128' if args.dtype == 'c128' else 'complex64'} "
-                               f"filterbank CAF (BASELINE configs[{cfg_idx}]), n={n_samp}, fs=48000",
-                   "surfaces_per_step": nsurf, "batch_per_gpu": args.batch,
-                   "rows_per_gpu": rows, "parallelism": f"doppler-row-shard x{world}" if world > 1 else "single",
-                   "peak_exchange": peak_exchange,
-                   "kernel_path": kernel_path, "device": devname, "cus": cu,
-                   "devices_visible_per_rank": ndev,
-                   "rank_devices": rank_devices if rank_devices is not None else [{"rank": 0, "device": 0, "visible": ndev}],
-                   "kernel_source_hash": kernel_source_hash(kernel_name)},
+        "config": config,
         "roofline": roof,
         "cpu_baseline": None,
         "extra": {},
     }
 
 
-def kernel_spread(extra, rank_kernel_ms):
-    """every rank's dominant-kernel time, and a flag when they differ by more than 10 % (a slow or throttled device, a rank that
-    did less work: the max-over-ranks clock hides which)"""
-    extra["rank_kernel_ms"] = rank_kernel_ms
+def kernel_spread(rank_kernel_ms):
+    """every rank's dominant-kernel time, their spread, and a flag when they differ by more than 10 % (a slow or throttled
+    device, a rank that did less work: the max-over-ranks clock hides which) -> the three `config` entries"""
+    out = {"rank_kernel_ms": list(rank_kernel_ms), "rank_kernel_ms_spread": None, "rank_kernel_ms_flag": None}
     good = [k for k in rank_kernel_ms if k and k > 0]
     if len(good) >= 2:
         spread = (max(good) - min(good)) / min(good)
-        extra["rank_kernel_ms_spread"] = spread
+        out["rank_kernel_ms_spread"] = spread
         if spread > KERNEL_SPREAD_FLAG:
-            extra["rank_kernel_ms_flag"] = (f"the ranks' row-kernel times differ by {spread * 100:.1f} % (> {KERNEL_SPREAD_FLAG * 100:.0f} %): "
-                                            f"slowest rank {rank_kernel_ms.index(max(good))}, fastest {rank_kernel_ms.index(min(good))}")
+            out["rank_kernel_ms_flag"] = (f"ranks' row-kernel times differ by {spread * 100:.1f} % (> {KERNEL_SPREAD_FLAG * 100:.0f} %): "
+                                          f"slowest {rank_kernel_ms.index(max(good))}, fastest {rank_kernel_ms.index(min(good))}")
+    return out
 
 
 # ---------------------------------------------------------------------------- in-process --
+MULTI_TIMEOUT_S = 60.0   # caf_multi_surface_set_timeout: a multi-device call that does not return within it fails with CAF_ERR_TIMEOUT
+
+
+def in_process_plumbing(args, devices):
+    """`--in-process --plumbing-only`: the one-process control path without a GPU -- the C ABI's own host rules
+    (caf_multi_surface_shard / caf_multi_surface_reduce: what the host join of caf_multi_surface_run_batch runs) on fabricated
+    shard peaks of G workers, then the record through the same assembler.  What the CPU suite and the fallback rehearsal run."""
+    import numpy as np
+    import caf_cookoff_amd as caf
+    G, F = len(devices), args.nfreq
+    B = 4 * G
+    wd = PhaseWatchdog(0, "cpu")
+    wd.enter("setup")
+    shards = [caf.multi_surface_shard(F, G, w) for w in range(G)]
+    want_row = [(37 * b) % F for b in range(B)]
+    rec = np.zeros((B, G), dtype=caf.Stream.PEAK_DTYPE)
+    for b in range(B):
+        for w, (lo, hi) in enumerate(shards):
+            own = lo <= want_row[b] < hi
+            rec[b, w] = (9.0 if own else 1.0 + w, 0.0, 100 + b if own else 0, want_row[b] if own else lo)
+    wd.enter("in_process_timed")
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps)):
+        got = [caf.multi_surface_reduce(rec[b]) for b in range(B)]
+    el = time.perf_counter() - t0
+    assert [int(g["row"]) for g in got] == want_row and [int(g["idx"]) for g in got] == [100 + b for b in range(B)]
+    res = assemble_line(args, F=F, n_samp=args.n, world=G, n_gpus_seen=len(set(devices)), nsurf=args.batch * G, rows=shards[0][1] - shards[0][0],
+                        K=args.steps, el=el, kern_ms=None, launches=0, kernel_name="caf::k_seq_rows<double, 15, caf::SeqIo<double> >",
+                        kernel_path="fused4096", devname="none (plumbing only)", cu=0, ndev=0,
+                        peak_exchange="host join of fabricated shard records (caf_multi_surface_reduce)",
+                        rank_devices=[{"worker": i, "device": d, "visible": 0} for i, d in enumerate(devices)],
+                        rank_kernel_ms=[0.5 * (w + 1) for w in range(G)])
+    res["value"] = None
+    res["plumbing_only"] = True
+    res["config"]["parallelism"] = f"doppler-row-shard x{G} (in-process: one host thread per device, no torch.distributed)"
+    res["extra"]["headline_blocks"] = block_stats([el / max(1, args.steps) * 1e3] * 2)
+    wd.enter("cpu_baseline")
+    res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(min(args.cpu_seconds, 1.0), args.cpu_threads)
+    wd.leave()
+    res["extra"]["phase_seconds"] = wd.phase_seconds()
+    with wd.line_lock:
+        wd.printed = True
+        emit_result(res)
+    return 0
+
+
 def in_process_main(args):
     """`bench.py --gpus N --in-process`: the headline (BASELINE configs[1]) as a compiled host reaches it -- one process, the C
-    ABI only: caf_multi_surface_run_batch over N devices, the peaks joined by in-library RCCL (bench_extras.in_process_headline).
+    ABI only: caf_multi_surface_run_batch over N devices, the peaks joined by in-library RCCL (bench_extras.in_process_headline);
+    the host join is measured instead when RCCL cannot be used (not loadable, communicator creation fails, repeated device ids)
+    and beside it under --sweeps.  Every multi-device call runs under the library's own deadline (MULTI_TIMEOUT_S).
     Prints ONE JSON line in the contract's format."""
+    devices = [int(x) for x in args.in_process_devices.split(",")] if args.in_process_devices else list(range(args.gpus))
+    if args.plumbing_only:
+        return in_process_plumbing(args, devices)
     import caf_cookoff_amd as caf
     lib = caf.load()
-    devices = [int(x) for x in args.in_process_devices.split(",")] if args.in_process_devices else list(range(args.gpus))
     wd = PhaseWatchdog(0, devices)
     wd.enter("setup")
     ndev = lib.caf_device_count()
@@ -215,26 +457,29 @@ def in_process_main(args):
         sys.exit(f"bench.py --in-process: device {max(devices)} wanted but only {ndev} device(s) are visible")
     G = len(devices)
     distinct = len(set(devices)) == G
-    forms = ("rccl_join", "host_join") if distinct else ("host_join",)
     K = args.steps
-    # (communicator creation, upload, warm-up, the correctness gate, the timed region and the blocks of both join forms: ~10 s when
-    #  healthy; ncclCommInitAll over a broken fabric is what this bounds)
+    # (communicator creation, upload, warm-up, the correctness gate, the timed region and the blocks: ~10 s when healthy;
+    #  ncclCommInitAll over a broken fabric is what the phase limit bounds, a stuck device what the library's deadline does)
     wd.enter("in_process_timed")
     res_forms = {}
-    head_name = forms[0]
+    head_name = "rccl_join" if distinct else "host_join"
+
+    def measure(form, blocks):
+        return in_process_headline(devices, args.batch, K, args.warmup, dtype=args.dtype, forms=(form,), blocks=blocks,
+                                   check=not args.no_check, timeout_s=MULTI_TIMEOUT_S, with_upload=args.sweeps)[form]
     try:
-        res_forms[head_name] = in_process_headline(devices, args.batch, K, args.warmup, dtype=args.dtype, forms=(head_name,),
-                                                   blocks=args.blocks, check=not args.no_check)[head_name]
+        res_forms[head_name] = measure(head_name, args.blocks)
     except caf.CafError as e:
-        if head_name != "rccl_join" or e.code != caf._lib.CAF_ERR_RCCL:
+        if head_name != "rccl_join" or e.code not in (caf._lib.CAF_ERR_RCCL, caf._lib.CAF_ERR_TIMEOUT):
             raise
-        # RCCL is not loadable here: say so, and measure the host join as the value
+        # RCCL is not usable here (not loadable, a communicator that cannot be made, a join that ran into the deadline):
+        # say so, and measure the host join as the value
         res_forms["rccl_join"] = {"error": str(e)}
+        print(f"bench.py --in-process: RCCL join not usable ({e}); measuring the host join", file=sys.stderr)
         head_name = "host_join"
-    for form in forms:
-        if form not in res_forms:
-            res_forms[form] = in_process_headline(devices, args.batch, K, args.warmup, dtype=args.dtype, forms=(form,),
-                                                  blocks=args.blocks if form == head_name else 0, check=not args.no_check)[form]
+        res_forms[head_name] = measure(head_name, args.blocks)
+    if args.sweeps and distinct and "host_join" not in res_forms:
+        res_forms["host_join"] = measure("host_join", 0)
     head = res_forms[head_name]
     wd.enter("setup")
     eng = caf.Engine(devices[0])
@@ -244,38 +489,51 @@ def in_process_main(args):
     plan0.close()
     eng.close()
     kms = head["worker_kernel_ms"]
-    exchange = {"rccl_join": "in-library RCCL: ONE grouped ncclAllReduce(max) over the %d shard values + ONE ncclAllReduce(min) over the "
-                             "(global_row << 32 | idx) keys per step, on the workers' streams (caf_multi_surface_run_batch, "
-                             "CAF_MULTI_REDUCE_RCCL); %d rank(s)" % (head["surfaces_per_step"], G),
+    exchange = {"rccl_join": "in-library RCCL: ONE grouped ncclAllReduce(max) + ONE ncclAllReduce(min key) per step over the %d shard "
+                             "values (caf_multi_surface_run_batch); %d rank(s)" % (head["surfaces_per_step"], G),
                 "host_join": "host join of the G shard records per surface (caf_multi_surface_reduce)"
-                             + ("" if distinct else "; repeated device ids: RCCL needs one rank per GPU")}[head_name]
+                             + ("" if distinct else "; repeated device ids: RCCL needs one rank per GPU")
+                             + ("; RCCL not usable: see bench_detail.json extra.forms.rccl_join" if distinct else "")}[head_name]
     res = assemble_line(args, F=400, n_samp=N_SAMP, world=G, n_gpus_seen=len(set(devices)), nsurf=head["surfaces_per_step"],
                         rows=head["rows_per_worker"][0], K=K, el=head["elapsed_s"], kern_ms=kms[0] if kms[0] > 0 else None,
                         launches=head["launches_timed"], kernel_name=head["kernel"], kernel_path=kernel_path, devname=devname, cu=cu,
                         ndev=ndev, peak_exchange=exchange,
-                        rank_devices=[{"worker": i, "device": d, "visible": ndev} for i, d in enumerate(devices)])
+                        rank_devices=[{"worker": i, "device": d, "visible": ndev} for i, d in enumerate(devices)],
+                        rccl_world={"world_size": G, "backend": "rccl (in-library, ncclCommInitAll)"} if head_name == "rccl_join" else None,
+                        rank_kernel_ms=kms)
     res["config"]["parallelism"] = f"doppler-row-shard x{G} (in-process: one host thread per device, no torch.distributed)"
-    res["config"]["workload"] += (f"; {head['surfaces_per_step']} surfaces per call of caf_multi_surface_run_batch, inputs resident in every "
-                                  "worker's HBM, slabs kept there, peaks to the host")
-    res["config"]["roofline_of"] = "worker 0's row shard (every worker launches the same kernel on its own rows)"
+    res["config"]["workload"] += "; one caf_multi_surface_run_batch call per step, inputs resident in every worker's HBM"
+    res["config"]["roofline_of"] = "worker 0's row shard"
     res["extra"]["forms"] = res_forms
     res["extra"]["headline_blocks"] = block_stats(head["blocks_ms"])
     res["extra"]["headline_blocks"]["how"] = f"{len(head['blocks_ms'])} further blocks of {K} calls after the reported one; `value` comes from the reported block only"
-    kernel_spread(res["extra"], kms)
+    # From here on the headline exists: a hang in what follows costs the run its status, not the measurement
+    import copy
+    headline_only = copy.deepcopy(res)
+
+    def print_headline_with_error():
+        if not wd.printed:
+            wd.printed = True
+            headline_only["extra"]["error"] = "a phase after the timed region did not finish within its limit; the headline was measured before it"
+            headline_only["extra"]["phase_seconds"] = wd.phase_seconds()
+            emit_result(headline_only)
+
     if not args.no_extra and args.dtype == "c128":
-        wd.enter("extras")
+        wd.enter("extras", on_expiry=print_headline_with_error)
         try:  # BASELINE configs[3] (ONE 4096 x 65536 complex64 surface per call) through the single-surface call of the same object
-            res["extra"]["configs3_single_call"] = in_process_config3(devices, steps=10, warmup=2, forms=("host_join",) + (("rccl_join",) if distinct else ()),
-                                                                       check=not args.no_check)
+            forms3 = (("rccl_join",) if head_name == "rccl_join" else ("host_join",)) + (("host_join",) if args.sweeps and head_name == "rccl_join" else ())
+            res["extra"]["configs3_single_call"] = in_process_config3(devices, steps=10, warmup=2, forms=forms3, check=not args.no_check,
+                                                                       timeout_s=MULTI_TIMEOUT_S)
         except Exception as e:
             res["extra"]["configs3_single_call"] = {"error": f"{type(e).__name__}: {e}"}
-    wd.enter("cpu_baseline")
+    wd.enter("cpu_baseline", on_expiry=print_headline_with_error)
     res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_seconds, args.cpu_threads)
     wd.leave()
     res["extra"]["phase_seconds"] = wd.phase_seconds()
     with wd.line_lock:
-        wd.printed = True
-        emit_line(res)
+        if not wd.printed:
+            wd.printed = True
+            emit_result(res)
     return 0
 
 
@@ -289,7 +547,7 @@ def _test_stall(rank, phase, step):
 
 def plumbing_only(args):
     """The N>1 control path without a GPU: rendezvous over gloo, reduce fabricated shard peaks with
-    the product's reduce_global_peak, rank 0 prints the JSON line.  Same phases, same watchdog as a measured run."""
+    the product's reduce_global_peak, rank 0 prints the JSON line.  Same phases, same watchdog, same fallback as a measured run."""
     import torch
     import torch.distributed as dist
     from caf_cookoff_amd.dist import reduce_global_peak
@@ -297,35 +555,44 @@ def plumbing_only(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     wd = PhaseWatchdog(rank, "cpu")
+    fb = RankFallback(args, rank, world)
+    if fb.enabled:
+        wd.rescue = fb.run
     wd.enter("rendezvous")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", timeout=timedelta(seconds=RENDEZVOUS_TIMEOUT_S))
-    wd.enter("setup")
-    F, nsurf = args.nfreq, 4 * world
-    lo, hi = shard_range(F, rank, world)
-    # surface b peaks on global row (37*b) % F; ranks that do not own the row report a lower local peak
-    want_row = torch.tensor([(37 * b) % F for b in range(nsurf)], dtype=torch.int64)
-    mine = (want_row >= lo) & (want_row < hi)
-    val = torch.where(mine, torch.full((nsurf,), 9.0, dtype=torch.float64), torch.full((nsurf,), 1.0 + rank, dtype=torch.float64))
-    row = torch.where(mine, want_row, torch.full((nsurf,), lo, dtype=torch.int64))
-    idx = torch.where(mine, torch.arange(nsurf) + 100, torch.zeros(nsurf, dtype=torch.int64))
-    wd.enter("warmup")
-    for i in range(max(1, args.warmup)):
-        _test_stall(rank, "warmup", i)
-        gmax, grow, gidx = reduce_global_peak(val, row, idx, method=args.peak_reduce)
-    wd.enter("check")
-    assert torch.equal(grow, want_row) and torch.equal(gidx, torch.arange(nsurf) + 100) and bool((gmax == 9.0).all())
-    wd.enter("timed")
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        _test_stall(rank, "timed", i)
-        gmax, grow, gidx = reduce_global_peak(val, row, idx, method=args.peak_reduce)
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
+    try:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", timeout=timedelta(seconds=RENDEZVOUS_TIMEOUT_S))
+        wd.enter("setup")
+        F, nsurf = args.nfreq, 4 * world
+        lo, hi = shard_range(F, rank, world)
+        # surface b peaks on global row (37*b) % F; ranks that do not own the row report a lower local peak
+        want_row = torch.tensor([(37 * b) % F for b in range(nsurf)], dtype=torch.int64)
+        mine = (want_row >= lo) & (want_row < hi)
+        val = torch.where(mine, torch.full((nsurf,), 9.0, dtype=torch.float64), torch.full((nsurf,), 1.0 + rank, dtype=torch.float64))
+        row = torch.where(mine, want_row, torch.full((nsurf,), lo, dtype=torch.int64))
+        idx = torch.where(mine, torch.arange(nsurf) + 100, torch.zeros(nsurf, dtype=torch.int64))
+        wd.enter("warmup")
+        for i in range(max(1, args.warmup)):
+            _test_stall(rank, "warmup", i)
+            gmax, grow, gidx = reduce_global_peak(val, row, idx, method=args.peak_reduce)
+        wd.enter("check")
+        assert torch.equal(grow, want_row) and torch.equal(gidx, torch.arange(nsurf) + 100) and bool((gmax == 9.0).all())
+        wd.enter("timed")
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            _test_stall(rank, "timed", i)
+            gmax, grow, gidx = reduce_global_peak(val, row, idx, method=args.peak_reduce)
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+    except Exception as e:   # a failure before the headline: the one-process path, if this run may fall back
+        if not fb.enabled:
+            raise
+        print(f"bench.py: rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+        os._exit(fb.run(f"rank {rank} failed before the headline: {type(e).__name__}: {e}"))
     wd.enter("multi_extras")
     n_seen = dist.get_world_size() if world > 1 else 1
     # the N > 1 extras' control path on fabricated numbers: ONE surface whose rows are sharded (peak on global row
@@ -366,15 +633,14 @@ def plumbing_only(args):
                             kernel_name="caf::k_seq_rows<double, 15, caf::SeqIo<double> >", kernel_path="fused4096",
                             devname="none (plumbing only)", cu=0, ndev=0,
                             peak_exchange=f"{args.peak_reduce}, on the main stream" if world > 1 else None,
-                            rank_devices=[{"rank": int(t[0]), "device": int(t[1]), "visible": int(t[2])} for t in allrd])
+                            rank_devices=[{"rank": int(t[0]), "device": int(t[1]), "visible": int(t[2])} for t in allrd],
+                            rccl_world={"world_size": n_seen, "backend": backend} if world > 1 else None,
+                            rank_kernel_ms=[float(t.item()) for t in allk])
         res["value"] = None
         res["plumbing_only"] = True
-        if world > 1:
-            kernel_spread(extra, [float(t.item()) for t in allk])
-            extra.update({"rccl_world": {"world_size": n_seen, "backend": backend},
-                          "headline_blocks": block_stats([el / max(1, args.steps) * 1e3] * 2)})
-        else:
-            extra = {"headline_blocks": block_stats([el / max(1, args.steps) * 1e3] * 2)}
+        if world == 1:
+            extra = {}
+        extra["headline_blocks"] = block_stats([el / max(1, args.steps) * 1e3] * 2)
         res["extra"] = extra
         wd.enter("cpu_baseline")
         res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(min(args.cpu_seconds, 1.0), args.cpu_threads)
@@ -382,7 +648,7 @@ def plumbing_only(args):
         res["extra"]["phase_seconds"] = wd.phase_seconds()
         with wd.line_lock:
             wd.printed = True
-            emit_line(res)
+            emit_result(res)
     wd.leave()
     return 0
 
@@ -429,154 +695,152 @@ def main():
         sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {ndev} device(s) are visible")
     # from here on no phase can hang silently: the watchdog names the rank, the device and the phase and ends the process
     wd = PhaseWatchdog(rank, f"cuda:{local_rank}")
-    wd.enter("rendezvous")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    rank_devices = [{"rank": 0, "device": local_rank, "visible": ndev}]
-    if coll:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        tmo = timedelta(seconds=RENDEZVOUS_TIMEOUT_S)   # (NCCL's default is 10 minutes: longer than the driver waits)
-        if rehearse:
-            dist.init_process_group("gloo", timeout=tmo)
-        else:
-            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
-        # every rank must see at least N devices (one process per GPU on ONE node); and who sits on which device
-        cdev = "cpu" if rehearse else dev
-        t = torch.tensor([ndev], dtype=torch.int64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if not rehearse and int(t.item()) < world:
-            sys.exit(f"bench.py: a rank sees only {int(t.item())} device(s) for a {world}-GPU run")
-        mine = torch.tensor([rank, local_rank, ndev], dtype=torch.int64, device=cdev)
-        parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
-        dist.all_gather(parts, mine)
-        rank_devices = [{"rank": int(p[0]), "device": int(p[1]), "visible": int(p[2])} for p in (q.cpu() for q in parts)]
-    n_gpus_seen = dist.get_world_size() if coll else 1
-
-    wd.enter("setup")
-    eng = caf.Engine(local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    cu, devname = eng.device_info()
-
-    F = args.nfreq
-    n_samp = args.n
-    freqs = caf.bench_shifts() if F == 400 else np.linspace(-100.0, 100.0, F, endpoint=False)
-    emul = args.emulate_rank_of if (args.emulate_rank_of > 1 and world == 1) else 0
-    lo, hi = caf.shard_range(F, 0, emul) if emul else caf.shard_range(F, rank, world)
-    rows = hi - lo
-    nsurf = args.batch * (emul or world)  # surfaces per step (whole job)
-    if emul:
-        args.no_check = args.no_extra = True   # (the planted peaks need not lie in shard 0; the extras are N = 1 measurements)
-    case = Case(eng, torch, dev, n_samp, freqs, args.dtype, nsurf, lo, hi)
-    plan = case.plan
-
-    # find_peak across the row shards (dist.reduce_global_peak with --peak-reduce: RCCL all-reduce(max) + all-reduce(min
-    # key), the form BASELINE's north_star names, or one all_gather of 16 B per surface and rank + a local reduction).
-    # Default: on the main stream, behind the step's find_peak kernel (~0.1 ms of a 3.9 ms step during which the chip
-    # idles: 63.7 k vs 65.5 k surfaces/s with one rank).  --overlap-peak-exchange: on a side stream behind an event
-    # recorded after this step's find_peak kernel, on alternating caf_peak buffers; the main stream waits for a
-    # buffer's previous exchange before the kernels write it again.
-    overlap = coll and not rehearse and args.overlap_peak_exchange
-    peaks = [case.peak, torch.empty_like(case.peak)] if coll else [case.peak]
-    side = torch.cuda.Stream(device=dev) if overlap else None
-    ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
-    ev_done = [torch.cuda.Event(), torch.cuda.Event()]
-    used = [False, False]
-    nstep = [0]
-
-    def step():
-        if not coll:
-            case.launch()
-            return None
-        k = nstep[0] & 1
-        nstep[0] += 1
-        pk = peaks[k]
-        if rehearse:
-            case.launch(peak=pk)
-            pk_c = pk.cpu()
-            pk_ci = pk_c.view(torch.int64)
-            return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2], method=args.peak_reduce, always_collective=True)
-        if not overlap:
-            case.launch(peak=pk)
-            pki = pk.view(torch.int64)
-            return reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=args.peak_reduce, always_collective=True)
-        main_stream = torch.cuda.current_stream()
-        if used[k]:
-            main_stream.wait_event(ev_done[k])
-        case.launch(peak=pk)
-        ev_ready[k].record(main_stream)
-        with torch.cuda.stream(side):
-            side.wait_event(ev_ready[k])
-            pki = pk.view(torch.int64)
-            out = reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=args.peak_reduce, always_collective=True)
-            ev_done[k].record(side)
-        used[k] = True
-        return out
-
-    def sync_all():
-        torch.cuda.synchronize()
+    fb = RankFallback(args, rank, world)
+    if fb.enabled:
+        wd.rescue = fb.run   # (phases before the headline only: PhaseWatchdog.PRE_HEADLINE)
+    try:
+        wd.enter("rendezvous")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        rank_devices = [{"rank": 0, "device": local_rank, "visible": ndev}]
         if coll:
-            dist.barrier()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            tmo = timedelta(seconds=RENDEZVOUS_TIMEOUT_S)   # (see RENDEZVOUS_TIMEOUT_S: the phase watchdog ends a hung rank first)
+            if rehearse:
+                dist.init_process_group("gloo", timeout=tmo)
+            else:
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+            # every rank must see at least N devices (one process per GPU on ONE node); and who sits on which device
+            cdev = "cpu" if rehearse else dev
+            t = torch.tensor([ndev], dtype=torch.int64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if not rehearse and int(t.item()) < world:
+                sys.exit(f"bench.py: a rank sees only {int(t.item())} device(s) for a {world}-GPU run")
+            mine = torch.tensor([rank, local_rank, ndev], dtype=torch.int64, device=cdev)
+            parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, mine)
+            rank_devices = [{"rank": int(p[0]), "device": int(p[1]), "visible": int(p[2])} for p in (q.cpu() for q in parts)]
+        n_gpus_seen = dist.get_world_size() if coll else 1
+
+        wd.enter("setup")
+        eng = caf.Engine(local_rank)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        cu, devname = eng.device_info()
+
+        F = args.nfreq
+        n_samp = args.n
+        freqs = caf.bench_shifts() if F == 400 else np.linspace(-100.0, 100.0, F, endpoint=False)
+        emul = args.emulate_rank_of if (args.emulate_rank_of > 1 and world == 1) else 0
+        lo, hi = caf.shard_range(F, 0, emul) if emul else caf.shard_range(F, rank, world)
+        rows = hi - lo
+        nsurf = args.batch * (emul or world)  # surfaces per step (whole job)
+        if emul:
+            args.no_check = args.no_extra = True   # (the planted peaks need not lie in shard 0; the extras are N = 1 measurements)
+        case = Case(eng, torch, dev, n_samp, freqs, args.dtype, nsurf, lo, hi)
+        plan = case.plan
+
+        # find_peak across the row shards (dist.reduce_global_peak with --peak-reduce: RCCL all-reduce(max) + all-reduce(min
+        # key), the form BASELINE's north_star names, or one all_gather of 16 B per surface and rank + a local reduction).
+        # Default: on the main stream, behind the step's find_peak kernel (~0.1 ms of a 3.9 ms step during which the chip
+        # idles: 63.7 k vs 65.5 k surfaces/s with one rank).  --overlap-peak-exchange: on a side stream behind an event
+        # recorded after this step's find_peak kernel, on alternating caf_peak buffers; the main stream waits for a
+        # buffer's previous exchange before the kernels write it again.
+        overlap = coll and not rehearse and args.overlap_peak_exchange
+        peaks = [case.peak, torch.empty_like(case.peak)] if coll else [case.peak]
+        side = torch.cuda.Stream(device=dev) if overlap else None
+        ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+        used = [False, False]
+        nstep = [0]
+
+        def step():
+            if not coll:
+                case.launch()
+                return None
+            k = nstep[0] & 1
+            nstep[0] += 1
+            pk = peaks[k]
+            if rehearse:
+                case.launch(peak=pk)
+                pk_c = pk.cpu()
+                pk_ci = pk_c.view(torch.int64)
+                return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2], method=args.peak_reduce, always_collective=True)
+            if not overlap:
+                case.launch(peak=pk)
+                pki = pk.view(torch.int64)
+                return reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=args.peak_reduce, always_collective=True)
+            main_stream = torch.cuda.current_stream()
+            if used[k]:
+                main_stream.wait_event(ev_done[k])
+            case.launch(peak=pk)
+            ev_ready[k].record(main_stream)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_ready[k])
+                pki = pk.view(torch.int64)
+                out = reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=args.peak_reduce, always_collective=True)
+                ev_done[k].record(side)
+            used[k] = True
+            return out
+
+        def sync_all():
             torch.cuda.synchronize()
+            if coll:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    def allreduce_max_time(seconds: float) -> float:
-        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if rehearse else dev)
-        if coll:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        def allreduce_max_time(seconds: float) -> float:
+            t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if rehearse else dev)
+            if coll:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
 
-    wd.enter("warmup")
-    out = None
-    for i in range(args.warmup):
-        _test_stall(rank, "warmup", i)
-        out = step()
-    sync_all()
-
-    # ---- correctness gate on the warmed-up result (cheap; outside the timed region) ----
-    wd.enter("check")
-    if not args.no_check:
-        if args.warmup == 0:
+        wd.enter("warmup")
+        out = None
+        for i in range(args.warmup):
+            _test_stall(rank, "warmup", i)
             out = step()
-        torch.cuda.synchronize()
-        if not coll:
-            g_idx, g_freq, _ = case.host_peaks()
-        else:
-            gmax, grow, gidx = out
-            g_idx = gidx.cpu().numpy()
-            g_freq = freqs[grow.cpu().numpy()]
-        case.check(g_idx, g_freq, 0.5 if F == 400 else abs(freqs[1] - freqs[0]))
-
-    # ---- timed region: exactly K steps between barriers --------------------------------
-    wd.enter("timed")
-    K = args.steps
-    sync_all()
-    plan.timing_begin()  # HIP events around the dominant kernel, on the launch stream
-    t0 = time.perf_counter()
-    for i in range(K):
-        _test_stall(rank, "timed", i)
-        step()
-    torch.cuda.synchronize()
-    if coll:
-        dist.barrier()
-        torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    kern_ms_total, launches = plan.timing_end()
-    el = allreduce_max_time(el)
-
-    kern_ms = kern_ms_total / max(1, launches)
-    # ---- ten further timed blocks of K steps: the spread of the step time, and enough GPU time for a sampler to see ----
-    wd.enter("blocks")
-    blocks_ms = []
-    for _ in range(max(0, args.blocks)):
         sync_all()
-        tb = time.perf_counter()
-        for _ in range(K):
+
+        # ---- correctness gate on the warmed-up result (cheap; outside the timed region) ----
+        wd.enter("check")
+        if not args.no_check:
+            if args.warmup == 0:
+                out = step()
+            torch.cuda.synchronize()
+            if not coll:
+                g_idx, g_freq, _ = case.host_peaks()
+            else:
+                gmax, grow, gidx = out
+                g_idx = gidx.cpu().numpy()
+                g_freq = freqs[grow.cpu().numpy()]
+            case.check(g_idx, g_freq, 0.5 if F == 400 else abs(freqs[1] - freqs[0]))
+
+        # ---- timed region: exactly K steps between barriers --------------------------------
+        wd.enter("timed")
+        K = args.steps
+        sync_all()
+        plan.timing_begin()  # HIP events around the dominant kernel, on the launch stream
+        t0 = time.perf_counter()
+        for i in range(K):
+            _test_stall(rank, "timed", i)
             step()
         torch.cuda.synchronize()
         if coll:
             dist.barrier()
             torch.cuda.synchronize()
-        blocks_ms.append(allreduce_max_time(time.perf_counter() - tb) / K * 1e3)
+        el = time.perf_counter() - t0
+        kern_ms_total, launches = plan.timing_end()
+        el = allreduce_max_time(el)
+
+    except Exception as e:   # a failure before the headline: the one-process path as a fresh child, if this run may fall back
+        if not fb.enabled:
+            raise
+        import traceback
+        traceback.print_exc()
+        os._exit(fb.run(f"rank {rank} failed before the headline: {type(e).__name__}: {e}"))
+    kern_ms = kern_ms_total / max(1, launches)
     # every rank's dominant-kernel time, so that a reader sees that every rank worked
+    wd.enter("blocks")
     rank_kernel_ms = [kern_ms]
     if coll:
         tk = torch.tensor([kern_ms], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -590,16 +854,12 @@ def main():
                             kern_ms=kern_ms, launches=launches, kernel_name=plan.kernel_name, kernel_path=plan.path,
                             devname=devname, cu=cu, ndev=ndev,
                             peak_exchange=(f"{args.peak_reduce}, {'overlapped on a side stream' if overlap else 'on the main stream'}"
-                                           if coll else None), rank_devices=rank_devices)
+                                           if coll else None), rank_devices=rank_devices,
+                            rccl_world={"world_size": dist.get_world_size(), "backend": dist.get_backend()} if coll else None,
+                            rank_kernel_ms=rank_kernel_ms)
         if emul:
             res["config"]["parallelism"] = (f"EMULATED rank 0 of {emul}: one GPU launching that rank's per-step shape "
                                             f"({nsurf} surfaces x rows [0, {rows})), no collective, not a scaling figure")
-        res["extra"]["headline_blocks"] = block_stats(blocks_ms)
-        res["extra"]["headline_blocks"]["how"] = (f"{len(blocks_ms)} further blocks of {K} steps after the reported one, each between "
-                                                  "barriers (max over ranks); `value` comes from the reported block only")
-        if coll:
-            kernel_spread(res["extra"], rank_kernel_ms)
-            res["extra"]["rccl_world"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend()}
 
     # From here on the headline exists: a hang in what follows still costs the run its status (3), but rank 0 prints the line
     # it measured, with the reason, before it leaves.
@@ -609,10 +869,28 @@ def main():
     def print_headline_with_error():
         if rank == 0 and not wd.printed:
             wd.printed = True
-            headline_only["extra"]["error"] = ("a phase after the timed region did not finish within its limit; the headline above "
+            headline_only["extra"]["error"] = ("a phase after the timed region did not finish within its limit; the headline "
                                                "was measured before it")
             headline_only["extra"]["phase_seconds"] = wd.phase_seconds()
-            emit_line(headline_only)
+            emit_result(headline_only)
+
+    # ---- further timed blocks of K steps: the spread of the step time, and enough GPU time for a sampler to see ----
+    wd.enter("blocks", on_expiry=print_headline_with_error)
+    blocks_ms = []
+    for _ in range(max(0, args.blocks)):
+        sync_all()
+        tb = time.perf_counter()
+        for _ in range(K):
+            step()
+        torch.cuda.synchronize()
+        if coll:
+            dist.barrier()
+            torch.cuda.synchronize()
+        blocks_ms.append(allreduce_max_time(time.perf_counter() - tb) / K * 1e3)
+    if rank == 0:
+        res["extra"]["headline_blocks"] = block_stats(blocks_ms)
+        res["extra"]["headline_blocks"]["how"] = (f"{len(blocks_ms)} further blocks of {K} steps after the reported one, each between "
+                                                  "barriers (max over ranks); `value` comes from the reported block only")
 
     # ---- live VALU issue ceiling of the shipped instruction stream (n = 4096 shapes) ----
     wd.enter("ceiling", on_expiry=print_headline_with_error)
@@ -656,7 +934,7 @@ def main():
         with wd.line_lock:   # from here on the main thread owns the line: a watchdog that fires now finds `printed` set
             if not wd.printed:
                 wd.printed = True
-                emit_line(res)
+                emit_result(res)
     wd.enter("finish")
     eng.close()
     if coll:

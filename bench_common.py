@@ -39,12 +39,167 @@ def guard_stdout():
 
 
 def emit_line(obj):
-    data = (json.dumps(obj) + "\n").encode()
+    data = (json.dumps(obj, allow_nan=False) + "\n").encode()
     sys.stdout.flush()
     if _REAL_STDOUT is None:
         os.write(1, data)
     else:
         os.write(_REAL_STDOUT, data)
+
+
+# The contract line is SMALL (round 5's grew to 21 KB and the driver could no longer recover it: BENCH_r05.json parsed = null).
+# Everything a run measures goes into the full record; the full record goes to bench_detail.json next to bench.py (and, as one
+# line, to stderr); the LAST -- and only -- stdout line is the compact form below: the contract's keys, `roofline`,
+# `cpu_baseline`, and one scalar pair per other config under `extra`.  tests/test_bench_launch.py holds it to LINE_LIMIT.
+LINE_LIMIT = 4096
+DETAIL_FILE = "bench_detail.json"
+_CONFIG_KEYS = ("workload", "surfaces_per_step", "batch_per_gpu", "rows_per_gpu", "parallelism", "peak_exchange", "kernel_path",
+                "device", "cus", "devices_visible_per_rank", "rank_devices", "rccl_world", "rank_kernel_ms", "rank_kernel_ms_spread",
+                "rank_kernel_ms_flag", "kernel_source_hash", "fallback_from", "child_rc", "roofline_of")
+_ROOFLINE_LINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel",
+                       "kernel_ms", "launches_timed", "algorithmic_bytes_per_launch", "frac_of_achievable_6.29TBs", "whole_step_frac")
+_CPU_LINE_KEYS = ("value", "unit", "cores", "kind", "ms_per_surface", "single_thread_ms_per_surface", "host_cpu", "sample")
+
+
+def _sig(x, digits=6):
+    """floats of the compact line: six significant digits (the full record keeps every digit)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{digits}g}")
+
+
+def _pick(d, keys, digits=6):
+    """scalars of `d` under `keys`; byte counts stay exact"""
+    return {k: (d[k] if k in ("traffic", "algorithmic_bytes_per_launch") else _sig(d[k], digits))
+            for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
+
+
+def compact_extra(extra):
+    """`extra` of the line: one scalar pair per other config; everything else stays in the detail file."""
+    out = {}
+    if not isinstance(extra, dict):
+        return out
+    hb = extra.get("headline_blocks")
+    if isinstance(hb, dict):
+        out["headline_blocks"] = _pick(hb, ("blocks", "ms_per_step_median", "ms_per_step_min", "ms_per_step_max"), 5)
+    picks = {"configs2_c64": ("value", "frac"), "configs3_c64_full": ("ms_per_step", "frac", "traffic_over_algorithmic"),
+             "configs3_c64_shard": ("ms_per_step", "frac"), "configs4_stream": ("value", "frac", "memcpy_nodes_value"),
+             "configs3_c64_sharded": ("value", "ms_per_surface", "rank0_frac", "global_peak_correct"),
+             "configs4_stream_surface_parallel": ("value", "tau_correct"),
+             "compiled_host_bench": ("batch_resident_surfaces_per_s", "literal_loop_ms_per_surface"),
+             "host_api": ("peaks_only_us", "with_surface_ms")}
+    for name, keys in picks.items():
+        v = extra.get(name)
+        if isinstance(v, dict):
+            out[name] = {"error": str(v["error"])[:120]} if "error" in v else _pick(v, keys, 5)
+            if name.startswith("configs3_c64_") and "ms_per_step" in out[name]:
+                out[name]["ms"] = out[name].pop("ms_per_step")
+    iph = extra.get("in_process_headline")
+    if isinstance(iph, dict):
+        head = iph.get("rccl_join") if isinstance(iph.get("rccl_join"), dict) and "value" in iph["rccl_join"] else iph.get("host_join")
+        out["in_process_headline"] = ({"value": _sig(head["value"], 5), "join": "rccl" if head is iph.get("rccl_join") else "host"}
+                                      if isinstance(head, dict) and "value" in head else {"error": str(iph.get("error", "no figure"))[:120]})
+    c3 = extra.get("configs3_single_call")
+    if isinstance(c3, dict):
+        f = c3.get("rccl_join") if isinstance(c3.get("rccl_join"), dict) else c3.get("host_join")
+        out["configs3_single_call"] = _pick(f, ("value", "ms_per_surface", "worker0_frac"), 5) if isinstance(f, dict) else \
+            {"error": str(c3.get("error", "no figure"))[:120]}
+    for k in ("error", "plumbing"):
+        if k in extra:
+            out[k] = str(extra[k])[:200] if k == "error" else extra[k]
+    ps = extra.get("phase_seconds")
+    if isinstance(ps, dict):
+        out["phase_seconds"] = {k: round(v, 2) for k, v in ps.items()}
+    return out
+
+
+def compact_line(res):
+    """the contract line of a full record (never larger than LINE_LIMIT: see shrink_to_limit)"""
+    line = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    cfg = res.get("config") or {}
+    c = {}
+    for k in _CONFIG_KEYS:
+        if k in cfg:
+            v = cfg[k]
+            if k == "rank_devices" and isinstance(v, list):
+                v = [{kk: d[kk] for kk in ("rank", "worker", "device") if kk in d} for d in v]
+            elif k == "rank_kernel_ms" and isinstance(v, list):
+                v = [_sig(x, 5) for x in v]
+            elif k == "fallback_from" and isinstance(v, dict):
+                v = {"path": v.get("path"), "rc": v.get("rc"), "stderr_tail": str(v.get("stderr_tail", ""))[-300:]}
+            elif isinstance(v, str):
+                v = v[:200]
+            c[k] = _sig(v)
+    line["config"] = c
+    roof = res.get("roofline") or {}
+    r = _pick(roof, _ROOFLINE_LINE_KEYS)
+    if isinstance(r.get("traffic_source"), str):
+        r["traffic_source"] = r["traffic_source"].split(" (")[0][:120]
+    if isinstance(roof.get("secondary"), dict):
+        r["secondary"] = _pick(roof["secondary"], ("bound", "ceiling_ms", "frac_of_ceiling", "ceiling_frac_of_hbm"), 5)
+    line["roofline"] = r
+    cb = res.get("cpu_baseline")
+    line["cpu_baseline"] = _pick(cb, _CPU_LINE_KEYS) if isinstance(cb, dict) else None
+    if line["cpu_baseline"] and isinstance(line["cpu_baseline"].get("sample"), str):
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:160]
+    line["extra"] = compact_extra(res.get("extra"))
+    for k in ("plumbing_only",):
+        if k in res:
+            line[k] = res[k]
+    return line
+
+
+def shrink_to_limit(line, limit=LINE_LIMIT):
+    """A line that would still exceed the limit loses `extra` entries, largest first (never a contract key): the driver
+    must be able to read the line whatever a future run adds to it."""
+    def size(o):
+        return len(json.dumps(o, allow_nan=False)) + 1
+    dropped = []
+    while size(line) > limit and any(k not in ("detail_file", "dropped") for k in line["extra"]):
+        k = max((k for k in line["extra"] if k not in ("detail_file", "dropped")), key=lambda k: size(line["extra"][k]))
+        del line["extra"][k]
+        dropped.append(k)
+        line["extra"]["dropped"] = dropped
+    return line
+
+
+def write_detail(res):
+    """the full record -> bench_detail.json next to bench.py (CAF_BENCH_DETAIL overrides; /tmp if the tree is read-only) and,
+    as ONE line, to stderr.  -> the path written, or None."""
+    text = json.dumps(res, allow_nan=False, default=str)
+    os.write(2, ("bench.py detail: " + text + "\n").encode())
+    for cand in (os.environ.get("CAF_BENCH_DETAIL"), str(ROOT / DETAIL_FILE), "/tmp/" + DETAIL_FILE):
+        if not cand:
+            continue
+        try:
+            Path(cand).write_text(text + "\n")
+            return cand
+        except OSError:
+            continue
+    return None
+
+
+def sanitize(o):
+    """NaN / inf have no JSON spelling: null them (the strict parser the tests use rejects the Python spellings)"""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {str(k): sanitize(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [sanitize(v) for v in o]
+    return o
+
+
+def emit_result(res):
+    """detail file + stderr copy of the full record, then the ONE stdout line."""
+    res = sanitize(res)
+    path = write_detail(res)
+    line = compact_line(res)
+    line["extra"]["detail_file"] = path
+    emit_line(shrink_to_limit(line))
 
 
 # ------------------------------------------------------------------------------ helpers --
@@ -280,6 +435,11 @@ class PhaseWatchdog:
             out[ph] = round(out.get(ph, 0.0) + s, 3)
         return out
 
+    # phases before the headline exists: an overrun there may be answered by `rescue` (bench.RankFallback.run: the one-process
+    # path as a fresh child on rank 0, the other ranks wait for its verdict) instead of leaving empty-handed
+    PRE_HEADLINE = ("rendezvous", "setup", "warmup", "check", "timed")
+    rescue = None   # callable(reason) -> exit status; set by bench.py for collective runs under an external launcher
+
     def _watch(self):
         while True:
             time.sleep(0.2)
@@ -287,18 +447,34 @@ class PhaseWatchdog:
                 ph, dl, lim, cb = self._phase, self._deadline, self._limit, self._cb
             if ph is None or time.monotonic() <= dl:
                 continue
+            status = 3
             try:
                 if cb is not None:
                     with self.line_lock:
                         cb()
             finally:
-                os.write(2, (f"bench.py: rank {self.rank} (device {self.device}) did not finish phase '{ph}' within {lim:g} s; "
-                             "leaving with status 3" + ("" if self.printed else " and without a result line") + "\n").encode())
-                os._exit(3)
+                what = f"rank {self.rank} (device {self.device}) did not finish phase '{ph}' within {lim:g} s"
+                if self.rescue is not None and ph in self.PRE_HEADLINE and not self.printed:
+                    os.write(2, f"bench.py: {what}\n".encode())
+                    try:
+                        status = int(self.rescue(what))
+                    except Exception as e:   # the rescue is best effort: the run still ends here, loudly
+                        os.write(2, f"bench.py: fallback failed: {type(e).__name__}: {e}\n".encode())
+                        status = 3
+                    os.write(2, f"bench.py: rank {self.rank} leaving with status {status} after the fallback\n".encode())
+                else:
+                    os.write(2, (f"bench.py: {what}; leaving with status 3" + ("" if self.printed else " and without a result line")
+                                 + "\n").encode())
+                os._exit(status)
 
 
 def under_rocprofiler() -> bool:
     """rocprofv3 preloads its tool library into the profiled program, and that library initialises the GPU before the program's
-    first line runs: from such a process no other GPU program may be started (tools/profile_run.sh, bench.self_launch)."""
+    first line runs: from such a process no other GPU program may be started (tools/profile_run.sh, bench.self_launch).
+    Detected by the preload itself -- LD_PRELOAD naming a rocprofiler library, or the variables through which the profiler's
+    launcher hands its tool library to the runtime -- not by any ROCPROF* variable a shell or a site profile may carry
+    (ROCPROFILER_LOG_LEVEL and the like say nothing about a preload)."""
     pre = os.environ.get("LD_PRELOAD", "")
-    return "rocprof" in pre or any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ)
+    if "rocprof" in pre:
+        return True
+    return any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"))

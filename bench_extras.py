@@ -211,68 +211,74 @@ def stream_run(plan, nd, hs, lags, total, nslots, batch, split, three_kernels=Fa
     return nsurf / best, best / nsurf * 1e6, f"{ok}/{nsurf}"
 
 
-def stream_case(eng, torch, freqs, total=1000):
+STREAM_FIXED_FORM = "batched20_2slots"
+STREAM_FORMS = (   # name, slots, surfaces per replay, split, three kernels, native loop, hipMemcpyAsync nodes
+    ("single_2slots", 2, 1, False, False, True, False), ("single_3slots", 3, 1, False, False, True, False),
+    ("single_4slots", 4, 1, False, False, True, False),
+    ("split4_2slots", 2, 4, True, False, True, False), ("batched4_2slots", 2, 4, False, False, True, False),
+    ("batched8_4slots", 4, 8, False, False, True, False),
+    ("batched20_2slots", 2, 20, False, False, True, False),
+    ("batched32_2slots", 2, 32, False, False, True, False),
+    ("batched20_2slots_memcpy_nodes", 2, 20, False, False, True, True),
+    ("batched8_4slots_memcpy_nodes", 4, 8, False, False, True, True),
+    ("batched1_2slots_memcpy_nodes", 2, 1, False, False, True, True),
+    ("single_2slots_three_kernels", 2, 1, False, True, True, False),
+    ("single_2slots_python_loop", 2, 1, False, False, False, False))
+STREAM_DEFAULT_FORMS = (STREAM_FIXED_FORM, STREAM_FIXED_FORM + "_memcpy_nodes")
+
+
+def stream_case(eng, torch, freqs, total=1000, sweeps=False):
     """BASELINE configs[4]: `total` back-to-back 400x8192 complex128 surfaces from host memory, double-
     buffered across pinned slots, one hipGraph replay per slot; surfaces stay on the device, (tau, f) + row
-    peaks come back.  Sustained surfaces/s over the whole run, H2D and D2H included.  A single-surface
-    chain is ONE kernel node (k_seq_surface: needle staging, haystack spectrum, rows and find_peak as roles
-    of one launch) while at most two surfaces are in flight, TWO nodes {staging + spectrum | rows +
-    find_peak} from three on; the host reads completion from a pinned sequence word.  Reported forms:
-      single_2slots / _3slots / _4slots   one surface per graph replay, native loop (caf_stream_run)
-      split4_2slots                   four independent single-surface chains per replay
-      batched4_2slots / batched8_4slots / batched20_2slots / batched32_2slots
-                                      one batched chain of four / eight / 20 / 32 surfaces per replay
-      batched20_2slots_memcpy_nodes / batched8_4slots_memcpy_nodes / batched1_2slots_memcpy_nodes
-                                      BASELINE configs[4] TO THE LETTER: the inputs cross PCIe as hipMemcpyAsync (copy-engine) nodes of
-                                      the slot's graph into device buffers, the results come back as hipMemcpyAsync nodes
-                                      (CAF_STREAM_MEMCPY_NODES); the fixed form, eight per replay on four slots, and one
-                                      surface per replay on two slots
-      single_2slots_three_kernels     round-2a form {spectrum, rows, find_peak} as three nodes (for comparison)
-      single_2slots_python_loop       submit / wait driven from Python, step by step (for comparison)
-    `value` = the FIXED form batched20_2slots (20 surfaces per graph replay, two slots: the plain double buffer of the config
-    text; 1000 surfaces = exactly 50 replays, no ragged last one), since round 5.  Why larger replays on two slots instead of
-    rounds 3-4's eight per replay on four: 8 surfaces are 3 200 rows = 6.25 rounds of the 512 persistent row workgroups (a seventh,
-    quarter-full round per launch: 141 us against 119 us at the batched rate), 20 are 16.7; and the row launch of a replay of 16
-    surfaces or more leaves 32 workgroup slots free, so that the other slot's staging + spectrum launch runs beside it instead
-    of in its tail (row workgroups hold every register of the CUs they fill; HISTORY.md R5.6: 32 per replay on two slots 53 k
-    surfaces/s without the free slots, 64-67 k with them).  tools/stream_1000.py, profiles/r05_stream/stream_1000.txt (1000
-    surfaces, median of 9 passes, each form visited twice): 20 x 2 slots 64.5-64.7 k, 25 x 2 64.0-64.3 k, 32 x 2 62.1-62.2 k (its
-    last replay is three quarters padding), 8 x 4 61.6-62.5 k; for long streams 32 x 2 is the flattest form
-    (tools/stream_form_stability.py, profiles/r05_stream/form_stability.txt: 64.2-64.6 k over six creations against 61.5-62.8 k
-    for 8 x 4 and 47-58 k for one surface per replay on four slots).  The other forms are reported beside it, never selected from."""
+    peaks come back.  Sustained surfaces/s over the whole run, H2D and D2H included.
+    A default run measures TWO forms:
+      batched20_2slots               `value`: the FIXED form -- one batched chain of 20 surfaces per graph replay on two slots
+                                     (the plain double buffer of the config text; 1000 surfaces = exactly 50 replays), the
+                                     kernels read and write mapped pinned host memory in place
+      batched20_2slots_memcpy_nodes  `memcpy_nodes_value`: BASELINE configs[4] TO THE LETTER -- the same form with the inputs
+                                     crossing PCIe as hipMemcpyAsync (copy-engine) nodes of the slot's graph into device buffers
+                                     and the results coming back as hipMemcpyAsync nodes (CAF_STREAM_MEMCPY_NODES)
+    `--sweeps` adds the comparison forms (never selected from): single_2slots / _3slots / _4slots (one surface per replay),
+    split4_2slots (four independent single-surface chains per replay), batched4_2slots / batched8_4slots / batched32_2slots,
+    batched8_4slots_memcpy_nodes / batched1_2slots_memcpy_nodes, single_2slots_three_kernels (round-2a form), single_2slots_python_loop
+    (submit / wait driven from Python), and `value_long_stream`: 32 per replay on two slots over 8 x `total` surfaces, the
+    flattest form for streams much longer than the config's 1000.
+    How the fixed form was chosen -- ON THIS WORKLOAD, 1000 surfaces, which 20 divides exactly (profiles/README.md
+    says so too): 8 surfaces are 3 200 rows = 6.25 rounds of the 512 persistent row workgroups (a seventh, quarter-full round per
+    launch), 20 are 16.7; and the row launch of a replay of 16 surfaces or more leaves 32 workgroup slots free, so that the other
+    slot's staging + spectrum launch runs beside it instead of in its tail (HISTORY.md R5.6).  tools/stream_sweep.py 1000,
+    profiles/r05_stream/stream_1000.txt (median of 9 passes, each form visited twice): 20 x 2 slots 64.5-64.7 k, 25 x 2
+    64.0-64.3 k, 32 x 2 62.1-62.2 k (its last replay is three quarters padding), 8 x 4 61.6-62.5 k; for long streams 32 x 2 is the
+    flattest form (profiles/r05_stream/form_stability.txt: 64.2-64.6 k over six creations)."""
     from caf_cookoff_amd.synth import make_batch
     plan = eng.plan(N_SAMP, freqs, FS)
     nd, hs, lags, _ = make_batch(64, N_SAMP, FS, seed0=5000)
     forms = {}
-    for name, nslots, batch, split, three, native, mc in (
-            ("single_2slots", 2, 1, False, False, True, False), ("single_3slots", 3, 1, False, False, True, False),
-            ("single_4slots", 4, 1, False, False, True, False),
-            ("split4_2slots", 2, 4, True, False, True, False), ("batched4_2slots", 2, 4, False, False, True, False),
-            ("batched8_4slots", 4, 8, False, False, True, False),
-            ("batched20_2slots", 2, 20, False, False, True, False),
-            ("batched32_2slots", 2, 32, False, False, True, False),
-            ("batched20_2slots_memcpy_nodes", 2, 20, False, False, True, True),
-            ("batched8_4slots_memcpy_nodes", 4, 8, False, False, True, True),
-            ("batched1_2slots_memcpy_nodes", 2, 1, False, False, True, True),
-            ("single_2slots_three_kernels", 2, 1, False, True, True, False),
-            ("single_2slots_python_loop", 2, 1, False, False, False, False)):
+    for name, nslots, batch, split, three, native, mc in STREAM_FORMS:
+        if not sweeps and name not in STREAM_DEFAULT_FORMS:
+            continue
         v, us, okc = stream_run(plan, nd, hs, lags, total, nslots, batch, split, three, native, memcpy_nodes=mc)
         forms[name] = {"value": v, "us_per_surface": us, "tau_correct": okc}
         if native:
             forms[name]["host_thread"] = dict(getattr(stream_run, "last_host_us", {}))
             forms[name].update(getattr(stream_run, "last_spread", {}))
+    long_stream = None
+    if sweeps:
+        v, us, okc = stream_run(plan, nd, hs, lags, 8 * total, 2, 32, False, False, True, passes=3)
+        long_stream = {"value": v, "form": "batched32_2slots", "surfaces": 8 * total, "tau_correct": okc}
     plan.close()
     abytes = algorithmic_bytes(1, 400, N_SAMP, "c128")
-    best = "batched20_2slots"
+    best = STREAM_FIXED_FORM
     return {"workload": f"{total} back-to-back 400x8192 complex128 surfaces from host memory, hipGraph replay per slot, "
                         "stage-in of inputs and stage-out of peaks included, surfaces left on the device (BASELINE configs[4]); "
-                        "`value`: the kernels read and write mapped pinned host memory in place; the literal form of the config text "
-                        "(hipMemcpyAsync nodes both ways) is reported beside it as forms.batched20_2slots_memcpy_nodes / "
-                        "batched8_4slots_memcpy_nodes / batched1_2slots_memcpy_nodes and as `memcpy_nodes_value`",
+                        "`value`: the kernels read and write mapped pinned host memory in place; `memcpy_nodes_value`: the literal "
+                        "form of the config text (hipMemcpyAsync nodes both ways)",
             "value": forms[best]["value"], "unit": "surfaces/s", "form": best, "forms": forms,
+            "form_selected_on": f"this workload ({total} surfaces: 20 divides it exactly); value_long_stream (--sweeps) is the steady-state form",
             "value_is": f"median of {forms[best].get('passes')} passes over the {total} pairs (one more pass before them warms up)",
             "value_min": forms[best].get("value_min"), "value_max": forms[best].get("value_max"),
-            "memcpy_nodes_value": forms["batched20_2slots_memcpy_nodes"]["value"],
+            "memcpy_nodes_value": forms[best + "_memcpy_nodes"]["value"],
+            "value_long_stream": long_stream,
             "algorithmic_bytes_per_surface": abytes, "frac": abytes * forms[best]["value"] / 1e9 / HBM_PEAK_GBS}
 
 
@@ -303,7 +309,7 @@ def multi_stream_case(freqs, devices, total=1000):
             "value_max": total / min(times), "tau_correct": f"{int(np.sum(peaks['idx'] == want))}/{total}"}
 
 
-def in_process_config3(devices, steps, warmup, forms=("host_join",), check=True):
+def in_process_config3(devices, steps, warmup, forms=("host_join",), check=True, timeout_s=None):
     """BASELINE configs[3] (ONE 4096 x 65536 complex64 surface) through the C ABI's caf_multi_surface_*: ONE process, worker r
     of G = len(devices) computes the Doppler rows [r*4096/G, (r+1)*4096/G) on devices[r] on its own host thread and keeps them
     in its HBM (CAF_MULTI_SURFACE_ON_DEVICE: the surface stays sharded); inputs are host pointers
@@ -321,6 +327,8 @@ def in_process_config3(devices, steps, warmup, forms=("host_join",), check=True)
     for form in forms:
         ms = caf.MultiSurface(devices, 32768, f3, FS, dtype="c64", rccl=(form == "rccl_join"), surface_on_device=True)
         try:
+            if timeout_s:
+                ms.set_timeout(timeout_s)
             for _ in range(warmup):
                 ms.run(nd[0], hs[0], want_surface=False)
             ms.timing_begin()
@@ -466,7 +474,8 @@ def multi_gpu_extras(args, eng, torch, dist, dev, rank, world, rehearse, freqs):
     return out
 
 
-def in_process_headline(devices, batch_per_gpu, steps, warmup, dtype="c128", forms=("host_join",), blocks=0, check=True):
+def in_process_headline(devices, batch_per_gpu, steps, warmup, dtype="c128", forms=("host_join",), blocks=0, check=True,
+                        timeout_s=None, with_upload=False):
     """BASELINE configs[1] (configs[2] with dtype c64) as a compiled host reaches it: ONE process, the C ABI only.
     caf_multi_surface_run_batch over G = len(devices) workers: a step covers B = batch_per_gpu * G surfaces (weak scaling: the
     per-GPU work is constant), worker r computes its Doppler rows [r*F/G, (r+1)*F/G) of EVERY surface in ONE launch of the row
@@ -475,8 +484,9 @@ def in_process_headline(devices, batch_per_gpu, steps, warmup, dtype="c128", for
       rccl_join   by ONE grouped ncclAllReduce(max) over the B shard values + ONE ncclAllReduce(min key) per call, inside the
                   library, on the workers' streams (distinct devices only).
     The inputs are uploaded (replicated on every worker) BEFORE the timed region and re-run from HBM (needles = haystacks =
-    NULL), as the contract prescribes; `with_upload` is the same call with the host-to-device copy of all B pairs inside it
-    (PCIe-inclusive: reported, never `value`).
+    NULL), as the contract prescribes; `with_upload` (--sweeps) is the same call with the host-to-device copy of all B pairs
+    inside it (PCIe-inclusive: reported, never `value`).  `timeout_s`: the library's own deadline for every call
+    (caf_multi_surface_set_timeout: a device that does not answer fails the call with CAF_ERR_TIMEOUT instead of hanging it).
     -> {form: {value surfaces/s, ms_per_step, per-worker row-kernel ms, join seconds, blocks, ...}}."""
     import statistics
     import numpy as np
@@ -492,10 +502,14 @@ def in_process_headline(devices, batch_per_gpu, steps, warmup, dtype="c128", for
     for form in forms:
         ms = caf.MultiSurface(devices, N_SAMP, freqs, FS, dtype=dtype, rccl=(form == "rccl_join"), surface_on_device=True)
         try:
+            if timeout_s:
+                ms.set_timeout(timeout_s)
             ms.run_batch(nd, hs, want_rows=False)                       # first call: allocations + upload
-            t0 = time.perf_counter()
-            ms.run_batch(nd, hs, want_rows=False)                       # steady-state call WITH the upload of all B pairs
-            with_upload_s = time.perf_counter() - t0
+            with_upload_s = None
+            if with_upload:
+                t0 = time.perf_counter()
+                ms.run_batch(nd, hs, want_rows=False)                   # steady-state call WITH the upload of all B pairs
+                with_upload_s = time.perf_counter() - t0
             pk = None
             for _ in range(max(1, warmup)):
                 _, _, pk = ms.run_batch(batch=B, want_rows=False)
@@ -528,7 +542,7 @@ def in_process_headline(devices, batch_per_gpu, steps, warmup, dtype="c128", for
                          "last_call": {"shards_ms": stats["shards_s"] * 1e3, "join_ms": stats["reduce_s"] * 1e3},
                          "with_upload": {"ms_per_step": with_upload_s * 1e3, "value": B / with_upload_s,
                                          "what": f"the same call with the host-to-device copy of all {B} pairs to every worker inside it "
-                                                 "(PCIe-inclusive; never `value`)"},
+                                                 "(PCIe-inclusive; never `value`)"} if with_upload_s else None,
                          "blocks_ms": blocks_ms,
                          "blocks_median_ms": statistics.median(blocks_ms) if blocks_ms else None,
                          "planted_peaks_found": ok,
@@ -543,8 +557,17 @@ def n1_extras(args, eng, torch, dev, local_rank, freqs, K, extra):
     import numpy as np
     import caf_cookoff_amd as caf
     torch.cuda.empty_cache()
+    legs, cur = {}, [None, time.perf_counter()]
+
+    def leg(name):
+        """wall seconds of every leg of the extras (full record: extra.extras_leg_seconds)"""
+        now = time.perf_counter()
+        if cur[0] is not None:
+            legs[cur[0]] = round(legs.get(cur[0], 0.0) + now - cur[1], 3)
+        cur[0], cur[1] = name, now
 
     def plan_case(name, n, freqs_x, dtype, batch, lo_x, hi_x, steps, warmup, cfg, ceiling=None):
+        leg(name)
         c = Case(eng, torch, dev, n, freqs_x, dtype, batch, lo_x, hi_x, seed0=3000)
         try:
             sec, kms, nl = c.timed(steps, warmup)
@@ -589,23 +612,34 @@ def n1_extras(args, eng, torch, dev, local_rank, freqs, K, extra):
         lo3, hi3 = caf.shard_range(4096, 3, 8)
         plan_case("configs3_c64_shard", 32768, f3, "c64", 1, lo3, hi3, 10, 2,
                   "rows [1536,2048) of 4096x65536 complex64: the shard rank 3 of 8 GPUs computes (BASELINE configs[3])")
-        extra["configs4_stream"] = stream_case(eng, torch, freqs, total=1000)
-        extra["configs4_stream"]["multi_ctx2_same_gpu"] = multi_stream_case(freqs, [local_rank, local_rank], total=1000)
+        leg("configs4_stream")
+        extra["configs4_stream"] = stream_case(eng, torch, freqs, total=1000, sweeps=args.sweeps)
+        if args.sweeps:
+            extra["configs4_stream"]["multi_ctx2_same_gpu"] = multi_stream_case(freqs, [local_rank, local_rank], total=1000)
     except Exception as e:
         extra["error"] = f"{type(e).__name__}: {e}"
-    # (a child process, timed from C: before the in-process legs below, whose 13 GB of slab allocations and frees would otherwise
-    #  sit between it and the streaming measurements it has always followed)
+    # (child processes, timed from C / C++: before the in-process leg below, whose 6.7 GB of slab allocations and frees would
+    #  otherwise sit between them and the streaming measurements they have always followed)
+    leg("host_api")
     extra["host_api"] = host_api_times()
+    leg("compiled_host_bench")
     extra["compiled_host_bench"] = compiled_host_bench(batch=args.batch)
+    if args.sweeps:
+        leg("in_process_multi")
+        try:
+            extra["in_process_multi"] = in_process_config3([local_rank], steps=10, warmup=2, forms=("host_join", "rccl_join"))
+            extra["in_process_multi"]["two_contexts_same_gpu"] = in_process_config3(
+                [local_rank, local_rank], steps=10, warmup=2, forms=("host_join",))["host_join"]
+        except Exception as e:
+            extra["in_process_multi"] = {"error": f"{type(e).__name__}: {e}"}
+    leg("in_process_headline")
     try:
-        extra["in_process_multi"] = in_process_config3([local_rank], steps=10, warmup=2, forms=("host_join", "rccl_join"))
-        extra["in_process_multi"]["two_contexts_same_gpu"] = in_process_config3(
-            [local_rank, local_rank], steps=10, warmup=2, forms=("host_join",))["host_join"]
-    except Exception as e:
-        extra["in_process_multi"] = {"error": f"{type(e).__name__}: {e}"}
-    try:
-        # the headline itself through the C ABI's batched row-shard call (what `bench.py --in-process` times), RCCL join with one rank
+        # the headline itself through the C ABI's batched row-shard call (what `bench.py --in-process` times), RCCL join with one
+        # rank (--sweeps: the host join and the call with the upload inside beside it)
         extra["in_process_headline"] = in_process_headline([local_rank], args.batch, steps=max(5, min(K, 30)), warmup=5,
-                                                           forms=("rccl_join", "host_join"), check=not args.no_check)
+                                                           forms=("rccl_join", "host_join") if args.sweeps else ("rccl_join",),
+                                                           check=not args.no_check, timeout_s=60.0, with_upload=args.sweeps)
     except Exception as e:
         extra["in_process_headline"] = {"error": f"{type(e).__name__}: {e}"}
+    leg(None)
+    extra["extras_leg_seconds"] = legs

@@ -23,6 +23,7 @@ CAF_ERR_NOMEM = 4
 CAF_ERR_NO_DEVICE = 5
 CAF_ERR_STATE = 6
 CAF_ERR_RCCL = 7
+CAF_ERR_TIMEOUT = 8
 
 CAF_C128 = 0
 CAF_C64 = 1
@@ -114,6 +115,7 @@ SYMBOLS = [
     ("caf_multi_surface_worker_info", _int, [_vp, _int, ctypes.POINTER(_int), ctypes.POINTER(_sz), ctypes.POINTER(_sz),
                                              ctypes.POINTER(ctypes.c_char_p)]),
     ("caf_multi_surface_run", _int, [_vp, _vp, _vp, _vp, _up, _vp, _pp]),
+    ("caf_multi_surface_set_timeout", _int, [_vp, ctypes.c_double]),
     ("caf_multi_surface_run_batch", _int, [_vp, _vp, _vp, _sz, _up, _vp, _pp]),
     ("caf_multi_surface_batch_results", _int, [_vp, _int, ctypes.POINTER(_sz), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                                ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),

@@ -543,6 +543,12 @@ class MultiSurface:
         self._rdt = np.float64 if dtype == "c128" else np.float32
         self._host_bufs = weakref.WeakValueDictionary()  # address -> live host_empty() buffer (close() refuses under them)
 
+    def set_timeout(self, seconds: float):
+        """``caf_multi_surface_set_timeout``: every later :meth:`run` / :meth:`run_batch` fails with ``CafError`` (code
+        ``CAF_ERR_TIMEOUT``) instead of waiting longer than ``seconds`` for a device; the object is unusable afterwards and
+        :meth:`close` does not wait for the device that did not answer.  0 = no deadline (the default)."""
+        check(self.lib.caf_multi_surface_set_timeout(self._h, float(seconds)), self.lib)
+
     def worker_info(self, worker: int):
         """-> (device, row_begin, row_end, row-kernel name)."""
         d, a, b = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_size_t()

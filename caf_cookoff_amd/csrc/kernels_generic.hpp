@@ -44,8 +44,9 @@ __global__ void k_apply_shift(const cpx<T> *__restrict__ in, size_t n, double ph
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    // sample 0 is multiplied by the recurrence's initial 1 + 0j (mod.rs:57-60): unchanged, also when fs == 0 made ph inf / NaN
-    out[i] = i == 0 ? in[0] : cmul(in[i], cis_f64<T>(ph * (double)i));
+    // sample 0 is multiplied by the recurrence's initial 1 + 0j with a full complex multiply (mod.rs:57-60) whatever ph is (fs == 0
+    // makes it inf / NaN): a finite sample comes out unchanged, an inf / NaN component spreads exactly as it does in the reference
+    out[i] = i == 0 ? cmul(in[0], cpx<T>{T(1), T(0)}) : cmul(in[i], cis_f64<T>(ph * (double)i));
 }
 
 // Row r of batch b: dst[(b*rows + r)*L + i] = i<n ? needle[b*n+i]*e^{j*ph[r]*i} : 0

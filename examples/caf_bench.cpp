@@ -76,6 +76,9 @@ int main(int argc, char **argv)
         bp.reset(new CafHipBatch(devices, n, shifts, 48000, /*rccl=*/false));
     }
     CafHipBatch &batch = *bp;
+    // a compiled host has no watchdog of its own: the library's deadline ends a call that waits for a device that does not
+    // answer (CAF_ERR_TIMEOUT -> the wrapper throws), instead of hanging this loop for ever
+    batch.set_timeout(60.0);
     auto got = batch.upload(nds, hss);  // allocations + first upload
     t0 = now_s();
     for (int i = 0; i < calls; ++i) got = batch.upload(nds, hss);
@@ -92,7 +95,7 @@ int main(int argc, char **argv)
     std::printf("{\"shape\": \"400x8192 complex128, chirp_0 pair\", \"gpus\": %d, \"peak_join\": \"%s\", \"literal_loop_ms_per_surface\": %.3f, "
                 "\"peaks_only_us_per_surface\": %.1f, \"batch\": %zu, \"batch_with_upload_ms_per_call\": %.3f, "
                 "\"batch_with_upload_surfaces_per_s\": %.0f, \"batch_resident_ms_per_call\": %.3f, \"batch_resident_surfaces_per_s\": %.0f, "
-                "\"published_rust_threadpool_ms_per_surface_R9_3900X\": 28}\n",
+                "\"call_timeout_s\": 60, \"published_rust_threadpool_ms_per_surface_R9_3900X\": 28}\n",
                 ndev, join, ms_literal, us_peaks, B, ms_upload, B / ms_upload * 1e3, ms_resident, B / ms_resident * 1e3);
     return 0;
 }

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CAF_ABI_VERSION 4
+#define CAF_ABI_VERSION 5
 
 enum caf_status {
     CAF_OK = 0,
@@ -48,7 +48,8 @@ enum caf_status {
     CAF_ERR_NOMEM = 4,
     CAF_ERR_NO_DEVICE = 5, /* no HIP device visible / device id out of range / the device is not gfx950 (MI355X) */
     CAF_ERR_STATE = 6,     /* call order violated (e.g. stream used after destroy) */
-    CAF_ERR_RCCL = 7       /* librccl could not be loaded or an RCCL call failed (CAF_MULTI_REDUCE_RCCL only) */
+    CAF_ERR_RCCL = 7,      /* librccl could not be loaded or an RCCL call failed (CAF_MULTI_REDUCE_RCCL only) */
+    CAF_ERR_TIMEOUT = 8    /* a multi-device call ran into the deadline of caf_multi_surface_set_timeout (ABI 5) */
 };
 
 enum caf_dtype {
@@ -250,7 +251,10 @@ enum caf_stream_flags {
     CAF_STREAM_ONE_KERNEL = 8,
     /* BASELINE configs[4] to the letter: the slot's inputs cross PCIe as hipMemcpyAsync (copy-engine) nodes of the graph into
      * device buffers and the peaks / row records come back as hipMemcpyAsync nodes, instead of kernels reading and writing the
-     * mapped pinned buffers in place (the default, faster: bench.py reports both).  Batched chains only. */
+     * mapped pinned buffers in place (the default, faster: bench.py reports both).  Accepted with every batch size and with
+     * CAF_STREAM_SPLIT; it always takes the {copy, spectrum, rows, find_peak, copy} chain -- never the single-launch surface,
+     * whose kernel reads and writes the pinned buffers itself -- so combining it with CAF_STREAM_ONE_KERNEL or
+     * CAF_STREAM_TWO_KERNELS is CAF_ERR_BAD_ARG. */
     CAF_STREAM_MEMCPY_NODES = 16
 };
 int caf_stream_create_ex(caf_plan *plan, size_t batch, int nslots, int want_surface, unsigned flags,
@@ -350,6 +354,18 @@ int caf_multi_surface_worker_info(const caf_multi_surface *h, int worker, int *d
                                   const char **kernel_name);
 int caf_multi_surface_run(caf_multi_surface *h, const void *needle, const void *haystack, void *surface,
                           uint64_t *row_idx, void *row_val, caf_peak *peak);
+/* A deadline for every later caf_multi_surface_run / _run_batch of the object (ABI 5).  The reference's join cannot wait for
+ * ever: `rx.recv().unwrap()` per row (mod.rs:452-457) panics when a pool worker died.  A GPU worker can stay silent instead
+ * (a device that never finishes its launch, a peer that never enters the RCCL exchange), so with seconds > 0 every wait
+ * inside a call -- each worker for its device, the caller for the worker threads, the RCCL join for every device -- is a poll
+ * against `seconds` from the start of the call.  On expiry the call returns CAF_ERR_TIMEOUT, caf_last_error_string() names the
+ * worker and its device, the object is unusable (every later run: CAF_ERR_STATE) and the work stays wherever it is: the
+ * library never resets a device or restarts anything.  caf_multi_surface_destroy then gives the devices 2 s to drain and
+ * LEAVES BEHIND (does not free, does not wait for) the context and buffers of a worker that has not; it reports that with
+ * CAF_ERR_TIMEOUT (the handle is invalid either way).  seconds == 0 (the default) means no deadline: plain blocking waits.
+ * What the deadline cannot bound: a runtime call that blocks while ENQUEUEING work (the caller then gets CAF_ERR_TIMEOUT
+ * 2 s after the deadline and the stuck thread is abandoned). */
+int caf_multi_surface_set_timeout(caf_multi_surface *h, double seconds);
 /* B surfaces per call -- the loop of benches/caf_bench.rs:150-168 (one caf_surface call per iteration, each fanning its rows out
  * over the pool and joining them, mod.rs:391-461) handed to the operator as ONE call, so that every device runs ONE launch of
  * its row kernel over its rows [row_begin, row_end) of ALL B surfaces instead of B launches with the chip idle in between.

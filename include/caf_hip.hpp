@@ -249,6 +249,9 @@ class CafHipMulti {
     CafHipMulti &operator=(const CafHipMulti &) = delete;
     ~CafHipMulti() { caf_multi_surface_destroy(h_); }  // frees the arena too
     int devices() const { return caf_multi_surface_devices(h_); }
+    // the join that cannot be skipped must not wait for ever either (mod.rs:452-457 panics on a dead worker): every later
+    // call throws (CAF_ERR_TIMEOUT) instead of waiting longer than `seconds` for a device; 0 = no deadline
+    void set_timeout(double seconds) { check(caf_multi_surface_set_timeout(h_, seconds), "caf_multi_surface_set_timeout"); }
 
     // mod.rs:26-27: rows in freq-list order; the global (freq, idx) of find_peak comes back in `peak`
     std::vector<CafSurfaceRow> caf_surface(const std::vector<Complex64> &needle, const std::vector<Complex64> &haystack,
@@ -320,6 +323,8 @@ class CafHipBatch {
     CafHipBatch(const CafHipBatch &) = delete;
     CafHipBatch &operator=(const CafHipBatch &) = delete;
     ~CafHipBatch() { caf_multi_surface_destroy(h_); }
+    // every later call throws (CAF_ERR_TIMEOUT) instead of waiting longer than `seconds` for a device; 0 = no deadline
+    void set_timeout(double seconds) { check(caf_multi_surface_set_timeout(h_, seconds), "caf_multi_surface_set_timeout"); }
 
     // needles / haystacks: B * n contiguous samples each; one call = upload + compute (PCIe-inclusive)
     std::vector<std::pair<double, std::size_t>> upload(const std::vector<Complex64> &needles, const std::vector<Complex64> &haystacks)

@@ -56,7 +56,7 @@ def test_streaming_double_buffer(eng, oracle, golden, manifest):
 
 
 def test_short_stream_soak():
-    """tools/stream_soak.py, 2048 surfaces x 6 rounds x 5 streaming forms x 2 dtypes: every row peak and record of
+    """tools/stream_sweep.py soak, 2048 surfaces x 6 rounds x 5 streaming forms x 2 dtypes: every row peak and record of
     every round equals round 0's bit for bit.  (What it caught in round 2: row words written to the pinned
     result buffers with plain stores reached the host after the sequence word of the launch, 1-3 surfaces in
     10^5; they are system-scope stores now.)"""
@@ -64,7 +64,7 @@ def test_short_stream_soak():
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    r = subprocess.run([sys.executable, str(root / "tools" / "stream_soak.py"), "2048", "6"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, str(root / "tools" / "stream_sweep.py"), "soak", "2048", "6"], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "SOAK ok" in r.stdout, r.stdout + r.stderr
 

@@ -3,7 +3,7 @@
 of k_seq_surface, completion read from a pinned sequence word, row peaks written to pinned memory by the kernel):
 N calls over a cycle of different inputs; EVERY result (row_idx, row_val, peak) must equal the bits of the first
 round.  A result that reached the host after the sequence word would show up here (the streaming path's soak,
-tools/stream_soak.py, found exactly that class of bug once).   usage: host_api_soak.py [calls] [dtype]"""
+tools/stream_sweep.py soak, found exactly that class of bug once).   usage: host_api_soak.py [calls] [dtype]"""
 import sys
 import time
 from pathlib import Path
