@@ -329,7 +329,10 @@ ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffi
                  "kernel_ms", "launches_timed", "algorithmic_bytes_per_launch", "frac_of_achievable_6.29TBs", "whole_step_frac")
 MULTI_EXTRA_KEYS = ("headline_blocks", "configs3_c64_sharded", "configs4_stream_surface_parallel")
 # who sat where and that every rank worked: in `config`, which the driver's record keeps whole (`extra` it reduces to a key list)
-RANK_EVIDENCE_KEYS = ("rank_devices", "rccl_world", "rank_kernel_ms", "rank_kernel_ms_spread", "rank_kernel_ms_flag")
+# (rounds 1-4's driver records kept the SCALAR entries of `config`; so the same facts are there as scalars too: world size,
+#  backend, "rank:device" pairs as one string, the smallest and largest kernel time, how many ranks reported one)
+RANK_EVIDENCE_KEYS = ("rank_devices", "rank_device_list", "rccl_world", "rccl_world_size", "rccl_backend", "rank_kernel_ms",
+                      "rank_kernel_ms_min", "rank_kernel_ms_max", "ranks_with_kernel_time", "rank_kernel_ms_spread", "rank_kernel_ms_flag")
 KERNEL_SPREAD_FLAG = 0.10   # config.rank_kernel_ms_flag when (max - min) / min of the ranks' row-kernel times exceeds this
 
 
@@ -360,7 +363,10 @@ def assemble_line(args, *, F, n_samp, world, n_gpus_seen, nsurf, rows, K, el, ke
               "devices_visible_per_rank": ndev,
               "rank_devices": rank_devices if rank_devices is not None else [{"rank": 0, "device": 0, "visible": ndev}],
               "rccl_world": rccl_world,
+              "rccl_world_size": rccl_world["world_size"] if rccl_world else None,
+              "rccl_backend": rccl_world["backend"] if rccl_world else None,
               "kernel_source_hash": kernel_source_hash(kernel_name)}
+    config["rank_device_list"] = ",".join(f"{d.get('rank', d.get('worker'))}:{d['device']}" for d in config["rank_devices"])
     config.update(kernel_spread(rank_kernel_ms if rank_kernel_ms is not None else [kern_ms]))
     return {
         "metric": "CAF surfaces/sec (400 freqs x 8192 samp, c128)"
@@ -379,8 +385,10 @@ def assemble_line(args, *, F, n_samp, world, n_gpus_seen, nsurf, rows, K, el, ke
 def kernel_spread(rank_kernel_ms):
     """every rank's dominant-kernel time, their spread, and a flag when they differ by more than 10 % (a slow or throttled
     device, a rank that did less work: the max-over-ranks clock hides which) -> the three `config` entries"""
-    out = {"rank_kernel_ms": list(rank_kernel_ms), "rank_kernel_ms_spread": None, "rank_kernel_ms_flag": None}
     good = [k for k in rank_kernel_ms if k and k > 0]
+    out = {"rank_kernel_ms": list(rank_kernel_ms), "rank_kernel_ms_min": min(good) if good else None,
+           "rank_kernel_ms_max": max(good) if good else None, "ranks_with_kernel_time": len(good),
+           "rank_kernel_ms_spread": None, "rank_kernel_ms_flag": None}
     if len(good) >= 2:
         spread = (max(good) - min(good)) / min(good)
         out["rank_kernel_ms_spread"] = spread

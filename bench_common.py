@@ -54,8 +54,9 @@ def emit_line(obj):
 LINE_LIMIT = 4096
 DETAIL_FILE = "bench_detail.json"
 _CONFIG_KEYS = ("workload", "surfaces_per_step", "batch_per_gpu", "rows_per_gpu", "parallelism", "peak_exchange", "kernel_path",
-                "device", "cus", "devices_visible_per_rank", "rank_devices", "rccl_world", "rank_kernel_ms", "rank_kernel_ms_spread",
-                "rank_kernel_ms_flag", "kernel_source_hash", "fallback_from", "child_rc", "roofline_of")
+                "device", "cus", "devices_visible_per_rank", "rank_devices", "rank_device_list", "rccl_world", "rccl_world_size",
+                "rccl_backend", "rank_kernel_ms", "rank_kernel_ms_min", "rank_kernel_ms_max", "ranks_with_kernel_time",
+                "rank_kernel_ms_spread", "rank_kernel_ms_flag", "kernel_source_hash", "fallback_from", "child_rc", "roofline_of")
 _ROOFLINE_LINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel",
                        "kernel_ms", "launches_timed", "algorithmic_bytes_per_launch", "frac_of_achievable_6.29TBs", "whole_step_frac")
 _CPU_LINE_KEYS = ("value", "unit", "cores", "kind", "ms_per_surface", "single_thread_ms_per_surface", "host_cpu", "sample")

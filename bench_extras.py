@@ -135,7 +135,9 @@ def host_api_times(reps=200):
 def compiled_host_bench(batch=256, calls=10):
     """examples/caf_bench.cpp (built as tests/cpp/caf_bench): the reference's bench loop (benches/caf_bench.rs:150-168) from a
     COMPILED host over the C ABI -- the literal one-call-per-iteration loop, the peaks-only call, and the loop as one
-    caf_multi_surface_run_batch call per `batch` pairs with the in-library RCCL join.  A child process without Python; it checks
+    caf_multi_surface_run_batch call per `batch` pairs (join: the in-library RCCL exchange when more than one GPU is visible,
+    the host join on one -- loading the system librccl and creating a communicator costs a cold child process ~5 s of a
+    default run, and `in_process_headline` already takes the one-rank RCCL join).  A child process without Python; it checks
     its own answers.  Reported, never `value` (its batched figure from HBM is the same measurement as `value`, one level down)."""
     exe = ROOT / "tests" / "cpp" / "caf_bench"
     try:
@@ -604,7 +606,7 @@ def n1_extras(args, eng, torch, dev, local_rank, freqs, K, extra):
                            "math-only ablation of k_duo_rows<float> (libcaf_hip_measure.so, CAF_STORE_MODE=33: the "
                            "product kernel body over a null memory policy), same batch"))
         f3 = np.arange(4096) * 0.05 - 102.4   # 0.05 Hz grid
-        plan_case("configs3_c64_full", 32768, f3, "c64", 1, 0, 4096, 5, 2,
+        plan_case("configs3_c64_full", 32768, f3, "c64", 1, 0, 4096, 10, 3,
                   "4096x65536 complex64 filterbank CAF, all rows on ONE GPU (BASELINE configs[3] shape)",
                   ceiling=("valu_plus_lds_exchanges", {"CAF_CHAIN_ABL": "31"},
                            "k_chain_rows<float, 14, 4> without global memory and workgroup barriers "

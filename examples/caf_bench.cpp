@@ -6,7 +6,9 @@
 //   (3) the loop handed over as ONE call per B pairs: caf_multi_surface_run_batch on every visible GPU (Doppler rows sharded
 //       over the GPUs, surfaces kept in HBM, peaks joined by in-library RCCL when there is more than one GPU), uploading the
 //       pairs with every call and from HBM
-// usage: caf_bench [data_dir] [B = 256] [calls = 20]
+// usage: caf_bench [data_dir] [B = 256] [calls = 20] [join = auto | rccl | host]
+//   join: auto = the in-library RCCL join when more than one GPU is visible, the host join on one GPU (loading librccl and
+//   creating a communicator costs a cold process about five seconds and a one-rank exchange moves nothing); rccl / host force one
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +27,8 @@ int main(int argc, char **argv)
     const std::string dir = argc > 1 ? argv[1] : "tests/golden/data";
     const std::size_t B = argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 256;
     const int calls = argc > 3 ? std::atoi(argv[3]) : 20;
+    const std::string join_arg = argc > 4 ? argv[4] : "auto";
+    const double t_start = now_s();
     auto files = load_files(dir + "/chirp_0_raw.c64", dir + "/chirp_0_T+202samp_F+69.25Hz.c64");
     const auto &needle = files.first, &hay = files.second;
     const std::size_t n = needle.size();
@@ -65,16 +69,21 @@ int main(int argc, char **argv)
     const int ndev = caf_device_count();
     std::vector<int> devices;
     for (int d = 0; d < ndev; ++d) devices.push_back(d);
-    // the in-library RCCL join if librccl can be loaded (the library dlopen()s it), else the host join
+    // the in-library RCCL join (if librccl can be loaded: the library dlopen()s it), or the host join
     std::unique_ptr<CafHipBatch> bp;
-    const char *join = "rccl";
-    try {
-        bp.reset(new CafHipBatch(devices, n, shifts, 48000, /*rccl=*/true));
-    } catch (const std::runtime_error &e) {
-        std::fprintf(stderr, "RCCL join not available (%s): joining the peaks on the host\n", e.what());
-        join = "host";
-        bp.reset(new CafHipBatch(devices, n, shifts, 48000, /*rccl=*/false));
+    const bool want_rccl = join_arg == "rccl" || (join_arg == "auto" && ndev > 1);
+    const char *join = want_rccl ? "rccl" : "host";
+    const double t_create = now_s();
+    if (want_rccl) {
+        try {
+            bp.reset(new CafHipBatch(devices, n, shifts, 48000, /*rccl=*/true));
+        } catch (const std::runtime_error &e) {
+            std::fprintf(stderr, "RCCL join not available (%s): joining the peaks on the host\n", e.what());
+            join = "host";
+        }
     }
+    if (!bp) bp.reset(new CafHipBatch(devices, n, shifts, 48000, /*rccl=*/false));
+    const double create_s = now_s() - t_create;
     CafHipBatch &batch = *bp;
     // a compiled host has no watchdog of its own: the library's deadline ends a call that waits for a device that does not
     // answer (CAF_ERR_TIMEOUT -> the wrapper throws), instead of hanging this loop for ever
@@ -95,7 +104,8 @@ int main(int argc, char **argv)
     std::printf("{\"shape\": \"400x8192 complex128, chirp_0 pair\", \"gpus\": %d, \"peak_join\": \"%s\", \"literal_loop_ms_per_surface\": %.3f, "
                 "\"peaks_only_us_per_surface\": %.1f, \"batch\": %zu, \"batch_with_upload_ms_per_call\": %.3f, "
                 "\"batch_with_upload_surfaces_per_s\": %.0f, \"batch_resident_ms_per_call\": %.3f, \"batch_resident_surfaces_per_s\": %.0f, "
-                "\"call_timeout_s\": 60, \"published_rust_threadpool_ms_per_surface_R9_3900X\": 28}\n",
-                ndev, join, ms_literal, us_peaks, B, ms_upload, B / ms_upload * 1e3, ms_resident, B / ms_resident * 1e3);
+                "\"call_timeout_s\": 60, \"create_s\": %.2f, \"process_s\": %.2f, \"published_rust_threadpool_ms_per_surface_R9_3900X\": 28}\n",
+                ndev, join, ms_literal, us_peaks, B, ms_upload, B / ms_upload * 1e3, ms_resident, B / ms_resident * 1e3,
+                create_s, now_s() - t_start);
     return 0;
 }

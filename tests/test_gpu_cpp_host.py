@@ -40,10 +40,10 @@ def test_cpp_bench_loop(built):
     loop as ONE caf_multi_surface_run_batch call per 64 pairs (RCCL join with this box's one GPU); it checks its own answers
     ((69.0, 202) and tau = 202 + b % 64 for the delayed copies) and prints one JSON line."""
     import json
-    r = subprocess.run([str(built / "caf_bench"), str(ROOT / "tests" / "golden" / "data"), "64", "5"], capture_output=True, text=True,
+    r = subprocess.run([str(built / "caf_bench"), str(ROOT / "tests" / "golden" / "data"), "64", "5", "rccl"], capture_output=True, text=True,
                        timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["batch"] == 64 and line["gpus"] >= 1
+    assert line["batch"] == 64 and line["gpus"] >= 1 and line["peak_join"] == "rccl" and line["call_timeout_s"] == 60
     assert 0 < line["batch_resident_ms_per_call"] <= line["batch_with_upload_ms_per_call"] * 1.5
     assert line["batch_resident_surfaces_per_s"] > 20 * 1e3 / line["literal_loop_ms_per_surface"]   # the batched call is the point
