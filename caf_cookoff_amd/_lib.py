@@ -13,7 +13,8 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libcaf_hip.so"
 # -DCAF_MEASURE build: rejected kernel variants + ablation switches (tools/ and the variant tests only)
-MEASURE_LIB_PATH = _HERE / "libcaf_hip_measure.so"
+# (CAF_HIP_MEASURE_LIB: another build of it, e.g. the host-sanitizer one of tools/asan_host_run.sh)
+MEASURE_LIB_PATH = Path(os.environ.get("CAF_HIP_MEASURE_LIB", _HERE / "libcaf_hip_measure.so"))
 
 CAF_OK = 0
 CAF_ERR_BAD_ARG = 1
