@@ -103,6 +103,7 @@ SYMBOLS = [
     ("caf_multi_stream_create", _int, [ctypes.POINTER(_int), _int, _sz, _dp, _sz, _u32, _int, _int, _int, ctypes.POINTER(_vp)]),
     ("caf_multi_stream_devices", _int, [_vp]),
     ("caf_multi_stream_run", _int, [_vp, _vp, _vp, _sz, _pp, _up, _vp]),
+    ("caf_multi_stream_set_timeout", _int, [_vp, ctypes.c_double]),
     ("caf_multi_stream_surface", _vp, [_vp, _int, _int]),
     ("caf_multi_stream_locate", _int, [_vp, _sz, _sz, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_sz),
                                        ctypes.POINTER(_int)]),

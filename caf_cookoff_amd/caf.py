@@ -440,8 +440,8 @@ class MultiStream:
     PEAK_DTYPE = Stream.PEAK_DTYPE
 
     def __init__(self, devices: Sequence[int], n: int, freqs_hz, fs: int, dtype: str = "c128", nslots: int = 3,
-                 want_surface: bool = False):
-        self.lib = _lib.load()
+                 want_surface: bool = False, lib=None):
+        self.lib = _lib.load(lib)
         self._h = None
         fr = np.ascontiguousarray(freqs_hz, dtype=np.float64)
         ids = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
@@ -455,6 +455,11 @@ class MultiStream:
         self.devices = [int(d) for d in devices]
         self._cdt = np.complex128 if dtype == "c128" else np.complex64
         self._rdt = np.float64 if dtype == "c128" else np.float32
+
+    def set_timeout(self, seconds: float):
+        """``caf_multi_stream_set_timeout``: every later :meth:`run` fails with ``CafError`` (``CAF_ERR_TIMEOUT``) instead of
+        waiting longer than ``seconds`` for a device; the object is unusable afterwards.  0 = no deadline (the default)."""
+        check(self.lib.caf_multi_stream_set_timeout(self._h, float(seconds)), self.lib)
 
     def run(self, needles, haystacks, want_rows: bool = False):
         nd = np.ascontiguousarray(needles, dtype=self._cdt)

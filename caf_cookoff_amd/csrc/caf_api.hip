@@ -66,7 +66,7 @@ static void measure_grid_reserve(size_t *) {}
 template <typename T> static bool measure_fused_rows(caf_plan *, FusedArgs<T> &, unsigned, size_t, int *) { return false; }
 template <typename T> static bool measure_chain_rows(caf_plan *, ChainArgs<T> &, const cpx<T> *, unsigned, int, int *) { return false; }
 static bool measure_surface_dev(caf_plan *, const void *, const void *, size_t, void *, uint64_t *, void *, int *) { return false; }
-static void measure_multi_stall(int, caf_ctx *, int) {}
+static void measure_multi_stall(int, caf_ctx *, int, hipStream_t = nullptr) {}
 static constexpr size_t upload_pieces_override() { return 0; }  // (measurement build: CAF_UPLOAD_PIECES, for the A/B of tools/upload_pieces.py)
 #endif
 

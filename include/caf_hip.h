@@ -303,6 +303,11 @@ int caf_multi_stream_create(const int *device_ids, int ndev, size_t n, const dou
 int caf_multi_stream_devices(const caf_multi_stream *ms);
 int caf_multi_stream_run(caf_multi_stream *ms, const void *needles, const void *haystacks, size_t count,
                          caf_peak *peaks, uint64_t *row_idx, void *row_val);
+/* A deadline for every later caf_multi_stream_run (ABI 5), with the meaning of caf_multi_surface_set_timeout below: each
+ * worker's waits for its slots are polls against `seconds` from the start of the run; on expiry the run returns
+ * CAF_ERR_TIMEOUT naming worker and device, later runs return CAF_ERR_STATE, and caf_multi_stream_destroy leaves behind
+ * (does not wait for) the workers of a device that has not drained 2 s later, reporting CAF_ERR_TIMEOUT.  0 = none. */
+int caf_multi_stream_set_timeout(caf_multi_stream *ms, double seconds);
 /* With want_surface != 0 every worker's slots keep their surfaces on the worker's device, as caf_stream_create does
  * (the reference's row record carries the magnitudes, mod.rs:17-22,156-161): caf_multi_stream_surface is the device
  * address of a worker's slot slab ([8][rows][2n] of the dtype's real type; NULL without surfaces), and

@@ -1,7 +1,9 @@
-"""caf_multi_surface_set_timeout (ABI 5): a multi-device call must not wait for ever for a device that does not answer.
+"""caf_multi_surface_set_timeout / caf_multi_stream_set_timeout (ABI 5): a multi-device call must not wait for ever for a device
+that does not answer.
 The reference's join panics on a dead worker (`rx.recv().unwrap()`, mod.rs:452-457); a GPU worker can stay silent instead.
 The MEASUREMENT build can make one: caf_debug_multi_stall(worker, ms, at) puts a kernel that sleeps for `ms` milliseconds
-(it ends by itself) on that worker's stream ahead of its row launch (at = 0) or ahead of its part of the RCCL join (at = 1).
+(it ends by itself) on that worker's stream ahead of its row launch (at = 0), ahead of its part of the RCCL join (at = 1), or on
+its first slot stream ahead of the first replay of a caf_multi_stream_run (at = 2).
 Two workers on the one GPU of this box (device ids 0, 0)."""
 import ctypes
 import time
@@ -131,6 +133,40 @@ def test_a_silent_peer_in_the_rccl_join_times_out(meng):
     assert e2.value.code == _lib.CAF_ERR_STATE
     rc, took_destroy = _destroy(ms)
     assert rc == _lib.CAF_OK and took_destroy < 3.0, (rc, took_destroy)
+
+
+def test_a_silent_device_under_the_surface_parallel_streams_times_out(meng):
+    """caf_multi_stream_run (whole surfaces round-robin, two workers on the one GPU): worker 1's first slot stream sleeps
+    2.5 s, the deadline is 1 s -> CAF_ERR_TIMEOUT naming worker 1, later runs CAF_ERR_STATE; destroy: the device has drained
+    inside the grace period, everything is released.  Healthy runs under a deadline return the bits of runs without one."""
+    import caf_cookoff_amd as caf
+    from caf_cookoff_amd import _lib
+    lib = _measure_lib()
+    fr, nd, hs, lags = _batch(37)
+    ms = caf.MultiStream([0, 0], 4096, fr, FS, nslots=2, lib=caf.MEASURE_LIB_PATH)
+    want, _, _ = ms.run(nd, hs)
+    assert np.array_equal(want["idx"], lags)
+    ms.set_timeout(1.0)
+    got, _, _ = ms.run(nd, hs)
+    assert got.tobytes() == want.tobytes()
+    assert lib.caf_debug_multi_stall(1, 2500, 2) == 0
+    t0 = time.perf_counter()
+    with pytest.raises(caf.CafError) as ei:
+        ms.run(nd, hs)
+    took = time.perf_counter() - t0
+    assert ei.value.code == _lib.CAF_ERR_TIMEOUT and "worker 1 (device 0)" in str(ei.value), str(ei.value)
+    assert 0.9 <= took < 2.4, took
+    with pytest.raises(caf.CafError) as e2:
+        ms.run(nd, hs)
+    assert e2.value.code == _lib.CAF_ERR_STATE
+    t0 = time.perf_counter()
+    rc = ms.lib.caf_multi_stream_destroy(ms._h)
+    ms._h = None
+    assert rc == _lib.CAF_OK and time.perf_counter() - t0 < 3.0, rc
+    ms2 = caf.MultiStream([0, 0], 4096, fr, FS, nslots=2)
+    again, _, _ = ms2.run(nd, hs)
+    assert again.tobytes() == want.tobytes()
+    ms2.close()
 
 
 def test_set_timeout_argument_checks_and_zero_means_none(eng):
