@@ -38,13 +38,19 @@ def guard_stdout():
         os.dup2(2, 1)
 
 
-def emit_line(obj):
-    data = (json.dumps(obj, allow_nan=False) + "\n").encode()
+def emit_line(obj, echo=True):
+    """the ONE stdout line -- and, last thing on stderr, a copy of it behind a prefix: whoever looks at the END of a capture
+    that puts stderr after stdout (the driver's record keeps 8 KB of such a tail) finds the line there too, not only the
+    end of the long detail record"""
+    text = json.dumps(obj, allow_nan=False)
+    data = (text + "\n").encode()
     sys.stdout.flush()
     if _REAL_STDOUT is None:
         os.write(1, data)
     else:
         os.write(_REAL_STDOUT, data)
+    if echo:
+        os.write(2, ("bench.py line: " + text + "\n").encode())
 
 
 # The contract line is SMALL (round 5's grew to 21 KB and the driver could no longer recover it: BENCH_r05.json parsed = null).
@@ -172,6 +178,11 @@ def write_detail(res):
     as ONE line, to stderr.  -> the path written, or None."""
     text = json.dumps(res, allow_nan=False, default=str)
     os.write(2, ("bench.py detail: " + text + "\n").encode())
+    if (ROOT / "gpurun_out").is_dir():   # (on a gpurun box: what is written there travels back with the call)
+        try:
+            (ROOT / "gpurun_out" / DETAIL_FILE).write_text(text + "\n")
+        except OSError:
+            pass
     for cand in (os.environ.get("CAF_BENCH_DETAIL"), str(ROOT / DETAIL_FILE), "/tmp/" + DETAIL_FILE):
         if not cand:
             continue

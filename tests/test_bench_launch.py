@@ -103,6 +103,10 @@ def test_the_line_is_one_small_strict_json_line(mode, tmp_path):
     det = [l for l in r.stderr.splitlines() if l.startswith("bench.py detail: ")]
     assert len(det) == 1 and _strict(det[0][len("bench.py detail: "):]) == r.detail
     assert r.detail["cpu_baseline"]["value"] == pytest.approx(cb["value"], rel=1e-5)
+    # ... and the LAST stderr line is a copy of the stdout line: a capture that appends stderr to stdout and keeps 8 KB of the
+    # end (the driver's record does) still shows the whole line, not only the end of the long detail record
+    merged_tail = (r.stdout + r.stderr).encode()[-8192:].decode(errors="replace")
+    assert "bench.py line: " + r.stdout.strip() in merged_tail and r.stderr.rstrip().splitlines()[-1] == "bench.py line: " + r.stdout.strip()
 
 
 def test_a_line_that_would_be_too_long_loses_extras_not_contract_keys():
