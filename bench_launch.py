@@ -150,7 +150,7 @@ def self_launch(args) -> int:
         line.setdefault("extra", {})
         emit_line(shrink_to_limit(line))
         return 0
-    if args.no_fallback:
+    if args.no_fallback or "CORRECTNESS GATE FAILED" in err:   # (a wrong answer is never papered over by another path's number)
         return rc if rc else 3
     return 0 if run_in_process_fallback(args, {"path": "torchrun", "rc": rc, "stderr_tail": err}) else (rc if rc else 3)
 

@@ -220,6 +220,14 @@ def test_a_failed_torchrun_tree_falls_back_to_the_one_process_path(tmp_path):
     assert "running the same headline through the one-process path" in r.stderr
 
 
+def test_a_failed_correctness_gate_is_never_answered_by_the_fallback(tmp_path):
+    """A WRONG ANSWER on the torchrun path must fail the run: neither layer starts the one-process path to print another path's
+    number over it.  (The gate is forced to fail on every rank; the ranks print a marker the launcher reads.)"""
+    r = _run(["--gpus", "2", "--steps", "2", "--plumbing-only", "--no-cpu-baseline"], {"CAF_BENCH_TEST_FAIL_GATE": "1"}, timeout=240, tmp=tmp_path)
+    assert r.returncode != 0 and not r.stdout, (r.returncode, r.stdout)
+    assert "CORRECTNESS GATE FAILED on rank" in r.stderr and "running the same headline through the one-process path" not in r.stderr
+
+
 def test_under_an_external_torchrun_rank0_falls_back_and_every_rank_leaves_with_its_status(tmp_path):
     """The driver starts torchrun itself (RANK / WORLD_SIZE set: bench.py's own launcher is not involved).  There a failure
     before the headline is answered by rank 0: its watchdog starts the one-process path as a fresh child and relays the
