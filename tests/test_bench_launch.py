@@ -301,3 +301,51 @@ def test_four_ranks_plumbing_only(tmp_path):
     assert [d["rank"] for d in line["config"]["rank_devices"]] == [0, 1, 2, 3] and len(line["config"]["rank_kernel_ms"]) == 4
     ex = r.detail["extra"]
     assert ex["configs3_c64_sharded"]["rows_rank0"] == 1024 and ex["configs4_stream_surface_parallel"]["pairs_rank0"] == 250
+
+
+def test_the_committed_full_records_compact_to_small_strict_lines():
+    """The full records of real runs (profiles/r06_misc/*_detail.json: default, --sweeps, --in-process, the N = 2 rehearsal) through
+    the same compaction as a live run: each line <= 4 096 bytes, strict JSON, with value / roofline.frac / cpu_baseline.value and
+    one scalar pair per other config -- a regression guard that needs no GPU (the --sweeps record is 22 KB; its line 2.6 KB)."""
+    sys.path.insert(0, str(ROOT))
+    import bench_common as bc
+    files = sorted((ROOT / "profiles" / "r06_misc").glob("*_detail.json"))
+    assert len(files) >= 4
+    for f in files:
+        res = json.loads(f.read_text())
+        line = bc.shrink_to_limit(bc.compact_line(bc.sanitize(res)))
+        text = json.dumps(line, allow_nan=False)
+        assert len(text) + 1 <= bc.LINE_LIMIT, (f.name, len(text))
+        back = _strict(text)
+        assert back["value"] == res["value"] and back["roofline"]["frac"] == pytest.approx(res["roofline"]["frac"], rel=1e-5)
+        assert back["cpu_baseline"]["value"] == pytest.approx(res["cpu_baseline"]["value"], rel=1e-5) and "dropped" not in back["extra"]
+        for k, v in back["extra"].items():
+            if isinstance(v, dict):
+                assert all(not isinstance(x, (dict, list)) for x in v.values()), (f.name, k)   # scalars only: nothing nested in the line
+    sweeps = json.loads((ROOT / "profiles" / "r06_misc" / "bench_n1_sweeps_detail.json").read_text())
+    assert len(sweeps["extra"]["configs4_stream"]["forms"]) == 13 and len(json.dumps(sweeps)) > 20000
+
+
+def test_stream_sweep_tool_parses_and_analyses_a_trace(tmp_path):
+    """tools/stream_sweep.py (fourteen round-2..5 scripts in one): its CSV analyses run without a GPU; the GPU commands at least
+    parse their arguments (presets, forms)."""
+    tool = str(ROOT / "tools" / "stream_sweep.py")
+    csvf = tmp_path / "kernel_trace.csv"
+    rows = ["Kernel_Name,Start_Timestamp,End_Timestamp,Queue_Id"]
+    t = 1000
+    for i in range(40):
+        rows.append(f"caf::k_seq_prepare<double>(args),{t},{t + 16000},1")
+        rows.append(f"caf::k_seq_rows<double>(args),{t + 17000},{t + 17000 + 290000},{1 + i % 2}")
+        t += 300000
+    csvf.write_text("\n".join(rows) + "\n")
+    r = subprocess.run([sys.executable, tool, "busy", str(csvf)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "row kernels over" in r.stdout and "at least one row kernel running" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, tool, "trace", str(csvf)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "k_seq_rows" in r.stdout and "median" in r.stdout
+    r = subprocess.run([sys.executable, tool, "rates", "--help"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "--preset" in r.stdout
+    sys.path.insert(0, str(ROOT / "tools"))
+    import stream_sweep
+    assert stream_sweep.parse_form("20:2:m") == dict(batch=20, nslots=2, split=False, one_kernel=False, two_kernels=False, three_kernels=False, memcpy_nodes=True)
+    assert stream_sweep.parse_form("4:2:s2")["split"] and stream_sweep.parse_form("4:2:s2")["two_kernels"]
+    assert set(stream_sweep.PRESETS) == {"1000", "stability", "native", "batch", "slots", "fixed", "probe", "reserve"}
