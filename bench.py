@@ -358,9 +358,12 @@ def in_process_main(args):
 
 # -------------------------------------------------------------------------- plumbing only --
 def _test_stall(rank, phase, step):
-    """CPU tests only: CAF_BENCH_TEST_STALL="rank=1,phase=timed,seconds=60" makes that rank sleep inside that phase's loop."""
+    """CPU tests only: CAF_BENCH_TEST_STALL="rank=1,phase=timed,seconds=60" makes that rank sleep inside that phase's loop;
+    "...,raise=1" makes it raise instead (a rank that fails alone while the others sit in the collective)."""
     spec = dict(kv.split("=") for kv in filter(None, os.environ.get("CAF_BENCH_TEST_STALL", "").split(",")))
     if spec and int(spec.get("rank", -1)) == rank and spec.get("phase") == phase and step == 1:
+        if spec.get("raise") == "1":
+            raise RuntimeError(f"CAF_BENCH_TEST_STALL: rank {rank} fails in phase '{phase}' (test)")
         time.sleep(float(spec.get("seconds", 60)))
 
 

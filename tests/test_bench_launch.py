@@ -253,6 +253,24 @@ def test_under_an_external_torchrun_rank0_falls_back_and_every_rank_leaves_with_
     assert r.returncode != 0 and not _json_lines(r.stdout)
 
 
+def test_a_rank_that_raises_alone_waits_for_rank0s_fallback_under_an_external_torchrun(tmp_path):
+    """The other way a run fails before the headline: rank 1 RAISES inside the timed loop (a device fault, an allocation) while
+    rank 0 sits in the collective.  Rank 1's handler does not leave -- it waits for rank 0's verdict; rank 0's watchdog runs into
+    the phase limit, starts the one-process path, relays the line; both ranks leave with status 0."""
+    detail = tmp_path / "detail.json"
+    port = subprocess.run([sys.executable, "-c", "import socket; s=socket.socket(); s.bind(('127.0.0.1',0)); print(s.getsockname()[1])"],
+                          capture_output=True, text=True).stdout.strip()
+    env = _env({"CAF_BENCH_TEST_STALL": "rank=1,phase=timed,raise=1", "CAF_BENCH_PHASE_LIMITS": "timed=5", "CAF_BENCH_FALLBACK_SETTLE_S": "1",
+                "OMP_NUM_THREADS": "1"}, detail)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--plumbing-only", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=240, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    (line,) = _json_lines(r.stdout)
+    assert line["config"]["fallback_from"]["path"].startswith("torchrun (external") and line["plumbing_only"]
+    assert "rank 1 failed before the headline: RuntimeError" in r.stderr and "waiting for rank 0's one-process fallback" in r.stderr
+
+
 def test_self_launch_is_refused_under_a_profiler_preload():
     """rocprofv3's preloaded tool library initialises the GPU before bench.py's first line: starting torchrun from such a
     process is the exec-after-GPU-init this pool forbids.  --in-process / --emulate-rank-of are the ways to profile.
