@@ -11,7 +11,9 @@ torchrun, no rendezvous, no torch.distributed) and its line is relayed with
 `config.fallback_from` = {path, rc, stderr_tail} of the path that failed.  Launched by torchrun
 directly (RANK/WORLD_SIZE set) it runs as one rank; there rank 0 starts the same fallback child
 itself when a phase BEFORE the headline fails or overruns (the other ranks wait for it, so the
-launcher does not end rank 0 early).  No process is ever re-exec'ed or restarted.
+launcher does not end rank 0 early).  A failed CORRECTNESS gate is never answered by the
+fallback (a wrong answer fails the run).  No process is ever re-exec'ed or restarted
+(bench_launch.py).
 
 A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 256)
 distinct (needle, haystack) pairs per GPU, each a 400 x 8192 complex128 filterbank CAF
@@ -54,7 +56,8 @@ Rank 0 prints ONE JSON line on stdout -- the LAST and only stdout line, at most 
                  timed from C / C++), `in_process_headline`; (N > 1) `configs3_c64_sharded` and
                  `configs4_stream_surface_parallel`; and `detail_file`.
 The FULL record (every figure, how it was taken, the per-form tables) goes to
-bench_detail.json next to this file and, as one line, to stderr.  `--sweeps` adds the
+bench_detail.json next to this file and, as one line, to stderr (whose LAST line is a copy of
+the stdout line, so that a capture that appends stderr to stdout still ends with it).  `--sweeps` adds the
 comparison forms (other streaming forms, both joins, `with_upload`, two contexts on one GPU) to
 the full record; they never enter the line.
 """
