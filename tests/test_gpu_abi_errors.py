@@ -236,6 +236,26 @@ def test_apply_freq_shift_with_fs_zero(dtype, eng, oracle, coracle):
     assert got[0] == x[0] and np.max(np.abs(got - want)) <= (1e-12 if dtype == "c128" else 2e-6)
 
 
+@pytest.mark.parametrize("dtype", ["c128", "c64"])
+def test_apply_freq_shift_non_finite_sample_zero_follows_the_reference(dtype, eng, coracle):
+    """mod.rs:57-60 multiplies sample 0 by the recurrence's initial 1 + 0j with a FULL complex multiply: an inf or NaN component
+    spreads exactly as (a*1 - b*0) + (a*0 + b*1) j says -- (inf + 1j) becomes inf + NaN j -- it is not passed through
+    (the round-5 kernel returned in[0] unchanged).  Finite samples are untouched by the same arithmetic."""
+    cdt = np.complex128 if dtype == "c128" else np.complex64
+    rng = np.random.default_rng(12)
+    for z0 in (complex(np.inf, 1.0), complex(2.0, -np.inf), complex(np.nan, 3.0), complex(-np.inf, np.inf), complex(-0.0, 0.0)):
+        x = (rng.standard_normal(64) + 1j * rng.standard_normal(64)).astype(cdt)
+        x[0] = z0
+        for fs in (FS, 0):
+            got = eng.apply_freq_shift(x, 7.5, fs).astype(np.complex128)
+            with np.errstate(invalid="ignore"):
+                want = coracle.apply_freq_shift(x.astype(np.complex128), 7.5, fs)
+            g0, w0 = got[:1].view(np.float64), want[:1].view(np.float64)
+            assert np.array_equal(np.isnan(g0), np.isnan(w0)) and np.array_equal(g0[~np.isnan(g0)], w0[~np.isnan(w0)]), (z0, fs, got[0], want[0])
+            if fs:
+                assert np.max(np.abs(got[1:] - want[1:])) <= (1e-12 if dtype == "c128" else 2e-6)
+
+
 def test_multi_surface_with_fs_zero(eng):
     import caf_cookoff_amd as caf
     rng = np.random.default_rng(8)
