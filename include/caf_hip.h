@@ -369,7 +369,11 @@ int caf_multi_surface_run(caf_multi_surface *h, const void *needle, const void *
  * LEAVES BEHIND (does not free, does not wait for) the context and buffers of a worker that has not; it reports that with
  * CAF_ERR_TIMEOUT (the handle is invalid either way).  seconds == 0 (the default) means no deadline: plain blocking waits.
  * What the deadline cannot bound: a runtime call that blocks while ENQUEUEING work (the caller then gets CAF_ERR_TIMEOUT
- * 2 s after the deadline and the stuck thread is abandoned). */
+ * 2 s after the deadline and the stuck thread is abandoned: it may still read the input arrays of that call when the
+ * runtime lets it go, so keep them alive until caf_multi_surface_destroy has returned CAF_OK -- for the rest of the process
+ * if it reports threads left behind).  After an ordinary timeout (a device that did not finish) nothing of the library
+ * touches the caller's memory again except the device work already queued, which writes only library-owned buffers and
+ * memory obtained from caf_multi_surface_host_alloc / _host_register (kept registered while that device is busy). */
 int caf_multi_surface_set_timeout(caf_multi_surface *h, double seconds);
 /* B surfaces per call -- the loop of benches/caf_bench.rs:150-168 (one caf_surface call per iteration, each fanning its rows out
  * over the pool and joining them, mod.rs:391-461) handed to the operator as ONE call, so that every device runs ONE launch of
