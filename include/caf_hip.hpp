@@ -200,6 +200,8 @@ class CafHipMultiStream {
     CafHipMultiStream &operator=(const CafHipMultiStream &) = delete;
     ~CafHipMultiStream() { caf_multi_stream_destroy(ms_); }
     int devices() const { return caf_multi_stream_devices(ms_); }
+    // every later run throws (CAF_ERR_TIMEOUT) instead of waiting longer than `seconds` for a device; 0 = no deadline
+    void set_timeout(double seconds) { check(caf_multi_stream_set_timeout(ms_, seconds), "caf_multi_stream_set_timeout"); }
     std::vector<std::pair<double, std::size_t>> run(const std::vector<std::vector<Complex64>> &needles,
                                                     const std::vector<std::vector<Complex64>> &haystacks)
     {

@@ -101,6 +101,7 @@ int main(int argc, char **argv)
         // the same ten pairs, whole surfaces round-robin over TWO contexts on GPU 0 (caf_multi_stream_*: the
         // surface-parallel multi-GPU driver, one host thread per context): same answers, in input order
         CafHipMultiStream multi({0, 0}, nd[0].size(), shifts, 48000, 2);
+        multi.set_timeout(30.0);  // ABI 5: a deadline changes nothing about a healthy run (polled waits, same answers)
         auto got2 = multi.run(nd, hs);
         const int before2 = failures;
         ASSERT_EQ(multi.devices(), 2);
@@ -150,6 +151,7 @@ int main(int argc, char **argv)
             auto want = CafHip::caf_surface(files.first, files.second, shifts, 48000);
             for (int workers = 2; workers <= 3; ++workers) {
                 CafHipMulti multi(std::vector<int>(workers, 0), files.first.size(), shifts, 48000);
+                if (workers == 3) multi.set_timeout(30.0);  // ABI 5: with and without a deadline, the same bits as the unsharded call
                 ASSERT_EQ(multi.devices(), workers);
                 std::pair<double, std::size_t> pk;
                 auto got = multi.caf_surface(files.first, files.second, &pk);
@@ -189,6 +191,7 @@ int main(int argc, char **argv)
             hss.push_back(files.second);
         }
         CafHipMulti multi(std::vector<int>(3, 0), nds[0].size(), shifts, 48000);
+        multi.set_timeout(30.0);
         std::vector<double> row_val;
         auto peaks = multi.find_peaks_batch(nds, hss, &row_val);
         ASSERT_EQ(peaks.size(), 5u);
