@@ -94,15 +94,17 @@ def test_two_rank_rehearsal_on_one_gpu():
 
 
 def test_a_stalled_rank_on_the_gpu_path_ends_the_run():
-    """the same run with rank 1 asleep inside the timed loop and the phase limit at 12 s: both ranks leave with status 3 after
-    naming rank, device and phase; no JSON line; well inside the bound."""
+    """the same run with rank 1 asleep inside the timed loop and the phase limit at 12 s: the ranks leave with status 3 after
+    naming rank, device and phase (at least the first to reach its limit gets to say so); no JSON line; well inside the bound."""
     t0 = time.time()
     r = _run(["--gpus", "2", "--batch", "32", "--steps", "10", "--blocks", "0", "--no-extra", "--no-cpu-baseline", "--no-fallback"],
              {"CAF_BENCH_REHEARSE_ON_ONE_GPU": "1", "CAF_BENCH_TEST_STALL": "rank=1,phase=timed,seconds=200",
               "CAF_BENCH_PHASE_LIMITS": "timed=12"}, timeout=300)
     assert r.returncode != 0 and not _lines(r.stdout), r.stdout
-    assert "rank 0 (device cuda:0) did not finish phase 'timed' within 12 s" in r.stderr, r.stderr[-1500:]
-    assert "rank 1 (device cuda:0) did not finish phase 'timed' within 12 s" in r.stderr
+    # both watchdogs run into the limit within a poll interval of each other; the launcher ends the remaining rank as soon as the
+    # first one has left, so the slower of the two may be gone before it has written its own line (1 soak run in 28 showed that)
+    said = [f"rank {k} (device cuda:0) did not finish phase 'timed' within 12 s" in r.stderr for k in (0, 1)]
+    assert any(said), r.stderr[-1500:]
     assert time.time() - t0 < 200
 
 
