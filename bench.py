@@ -261,9 +261,10 @@ def in_process_plumbing(args, devices):
 
 def in_process_main(args):
     """`bench.py --gpus N --in-process`: the headline (BASELINE configs[1]) as a compiled host reaches it -- one process, the C
-    ABI only: caf_multi_surface_run_batch over N devices, the peaks joined by in-library RCCL (bench_extras.in_process_headline);
-    the host join is measured instead when RCCL cannot be used (not loadable, communicator creation fails, repeated device ids)
-    and beside it under --sweeps.  Every multi-device call runs under the library's own deadline (MULTI_TIMEOUT_S).
+    ABI only: caf_multi_surface_run_batch over N devices, the peaks joined by in-library RCCL (bench_extras.in_process_headline).
+    The host join is measured FIRST (no communicator needed: a headline exists before RCCL is touched) and is the value when
+    RCCL cannot be used (not loadable, communicator creation fails or hangs, the exchange runs into the deadline, repeated
+    device ids).  Every multi-device call runs under the library's own deadline (MULTI_TIMEOUT_S).
     Prints ONE JSON line in the contract's format."""
     devices = [int(x) for x in args.in_process_devices.split(",")] if args.in_process_devices else list(range(args.gpus))
     if args.plumbing_only:
@@ -280,55 +281,75 @@ def in_process_main(args):
     G = len(devices)
     distinct = len(set(devices)) == G
     K = args.steps
-    # (communicator creation, upload, warm-up, the correctness gate, the timed region and the blocks: ~10 s when healthy;
-    #  ncclCommInitAll over a broken fabric is what the phase limit bounds, a stuck device what the library's deadline does)
-    wd.enter("in_process_timed")
+    eng = caf.Engine(devices[0])
+    cu, devname = eng.device_info()
+    plan0 = eng.plan(N_SAMP, caf.bench_shifts(), FS, dtype=args.dtype, row_begin=0, row_end=caf.multi_surface_shard(400, G, 0)[1])
+    kernel_path = plan0.path
+    plan0.close()
+    eng.close()
     res_forms = {}
-    head_name = "rccl_join" if distinct else "host_join"
 
     def measure(form, blocks):
         return in_process_headline(devices, args.batch, K, args.warmup, dtype=args.dtype, forms=(form,), blocks=blocks,
                                    check=not args.no_check, timeout_s=MULTI_TIMEOUT_S, with_upload=args.sweeps)[form]
-    try:
-        res_forms[head_name] = measure(head_name, args.blocks)
-    except caf.CafError as e:
-        if head_name != "rccl_join" or e.code not in (caf._lib.CAF_ERR_RCCL, caf._lib.CAF_ERR_TIMEOUT):
-            raise
-        # RCCL is not usable here (not loadable, a communicator that cannot be made, a join that ran into the deadline):
-        # say so, and measure the host join as the value
-        res_forms["rccl_join"] = {"error": str(e)}
-        print(f"bench.py --in-process: RCCL join not usable ({e}); measuring the host join", file=sys.stderr)
-        head_name = "host_join"
-        res_forms[head_name] = measure(head_name, args.blocks)
-    if args.sweeps and distinct and "host_join" not in res_forms:
-        res_forms["host_join"] = measure("host_join", 0)
-    head = res_forms[head_name]
-    wd.enter("setup")
-    eng = caf.Engine(devices[0])
-    cu, devname = eng.device_info()
-    plan0 = eng.plan(N_SAMP, caf.bench_shifts(), FS, dtype=args.dtype, row_begin=0, row_end=head["rows_per_worker"][0])
-    kernel_path = plan0.path
-    plan0.close()
-    eng.close()
-    kms = head["worker_kernel_ms"]
-    exchange = {"rccl_join": "in-library RCCL: ONE grouped ncclAllReduce(max) + ONE ncclAllReduce(min key) per step over the %d shard "
-                             "values (caf_multi_surface_run_batch); %d rank(s)" % (head["surfaces_per_step"], G),
-                "host_join": "host join of the G shard records per surface (caf_multi_surface_reduce)"
-                             + ("" if distinct else "; repeated device ids: RCCL needs one rank per GPU")
-                             + ("; RCCL not usable: see bench_detail.json extra.forms.rccl_join" if distinct else "")}[head_name]
-    res = assemble_line(args, F=400, n_samp=N_SAMP, world=G, n_gpus_seen=len(set(devices)), nsurf=head["surfaces_per_step"],
-                        rows=head["rows_per_worker"][0], K=K, el=head["elapsed_s"], kern_ms=kms[0] if kms[0] > 0 else None,
-                        launches=head["launches_timed"], kernel_name=head["kernel"], kernel_path=kernel_path, devname=devname, cu=cu,
-                        ndev=ndev, peak_exchange=exchange,
-                        rank_devices=[{"worker": i, "device": d, "visible": ndev} for i, d in enumerate(devices)],
-                        rccl_world={"world_size": G, "backend": "rccl (in-library, ncclCommInitAll)"} if head_name == "rccl_join" else None,
-                        rank_kernel_ms=kms)
-    res["config"]["parallelism"] = f"doppler-row-shard x{G} (in-process: one host thread per device, no torch.distributed)"
-    res["config"]["workload"] += "; one caf_multi_surface_run_batch call per step, inputs resident in every worker's HBM"
-    res["config"]["roofline_of"] = "worker 0's row shard"
-    res["extra"]["forms"] = res_forms
-    res["extra"]["headline_blocks"] = block_stats(head["blocks_ms"])
-    res["extra"]["headline_blocks"]["how"] = f"{len(head['blocks_ms'])} further blocks of {K} calls after the reported one; `value` comes from the reported block only"
+
+    def record_of(head_name):
+        """the full record with `head_name`'s measurement as the headline"""
+        head = res_forms[head_name]
+        kms = head["worker_kernel_ms"]
+        exchange = {"rccl_join": "in-library RCCL: ONE grouped ncclAllReduce(max) + ONE ncclAllReduce(min key) per step over the %d shard "
+                                 "values (caf_multi_surface_run_batch); %d rank(s)" % (head["surfaces_per_step"], G),
+                    "host_join": "host join of the G shard records per surface (caf_multi_surface_reduce)"
+                                 + ("" if distinct else "; repeated device ids: RCCL needs one rank per GPU")
+                                 + ("; RCCL join not usable: see bench_detail.json extra.forms.rccl_join" if distinct else "")}[head_name]
+        res = assemble_line(args, F=400, n_samp=N_SAMP, world=G, n_gpus_seen=len(set(devices)), nsurf=head["surfaces_per_step"],
+                            rows=head["rows_per_worker"][0], K=K, el=head["elapsed_s"], kern_ms=kms[0] if kms[0] > 0 else None,
+                            launches=head["launches_timed"], kernel_name=head["kernel"], kernel_path=kernel_path, devname=devname, cu=cu,
+                            ndev=ndev, peak_exchange=exchange,
+                            rank_devices=[{"worker": i, "device": d, "visible": ndev} for i, d in enumerate(devices)],
+                            rccl_world={"world_size": G, "backend": "rccl (in-library, ncclCommInitAll)"} if head_name == "rccl_join" else None,
+                            rank_kernel_ms=kms)
+        res["config"]["parallelism"] = f"doppler-row-shard x{G} (in-process: one host thread per device, no torch.distributed)"
+        res["config"]["workload"] += "; one caf_multi_surface_run_batch call per step, inputs resident in every worker's HBM"
+        res["config"]["roofline_of"] = "worker 0's row shard"
+        res["extra"]["forms"] = res_forms
+        res["extra"]["headline_blocks"] = block_stats(head["blocks_ms"])
+        res["extra"]["headline_blocks"]["how"] = (f"{len(head['blocks_ms'])} further blocks of {K} calls after the reported one; `value` comes from "
+                                                  "the reported block only")
+        return res
+
+    # The host join FIRST: it needs no communicator, so a measured headline exists before RCCL is touched.  This path is also the
+    # fallback of a torchrun path that failed -- quite possibly for a reason RCCL shares -- and ncclCommInitAll over a broken fabric
+    # is a call nothing inside the library can bound (the exchange itself is bounded by the library's deadline): if the RCCL leg
+    # does not come back within its phase limit, the host-join headline is printed with the reason.
+    wd.enter("in_process_timed")
+    head_name = "host_join"
+    res_forms["host_join"] = measure("host_join", args.blocks if not distinct else 0)
+    if distinct:
+        provisional = record_of("host_join")
+
+        def print_provisional():
+            if not wd.printed:
+                wd.printed = True
+                provisional["extra"]["error"] = ("the in-library RCCL join (communicator creation or exchange) did not finish within its phase "
+                                                 "limit; this is the host join measured before it")
+                provisional["extra"]["phase_seconds"] = wd.phase_seconds()
+                emit_result(provisional)
+
+        wd.enter("in_process_rccl", on_expiry=print_provisional)
+        try:
+            res_forms["rccl_join"] = measure("rccl_join", args.blocks)
+            head_name = "rccl_join"
+        except caf.CafError as e:
+            if e.code not in (caf._lib.CAF_ERR_RCCL, caf._lib.CAF_ERR_TIMEOUT):
+                raise
+            # RCCL is not usable here (not loadable, a communicator that cannot be made, a join that ran into the deadline):
+            # say so; the host join is the value (measured again, with its further blocks)
+            res_forms["rccl_join"] = {"error": str(e)}
+            print(f"bench.py --in-process: RCCL join not usable ({e}); the host join is the value", file=sys.stderr)
+            wd.enter("in_process_timed")
+            res_forms["host_join"] = measure("host_join", args.blocks)
+    res = record_of(head_name)
     # From here on the headline exists: a hang in what follows costs the run its status, not the measurement
     import copy
     headline_only = copy.deepcopy(res)

@@ -410,7 +410,7 @@ class PhaseWatchdog:
     #  are sized so that a rank stuck in any ONE phase leaves well inside a 600-second outer limit)
     LIMITS = {"rendezvous": 150.0, "setup": 180.0, "warmup": 120.0, "check": 90.0, "timed": 150.0, "blocks": 180.0,
               "ceiling": 120.0, "extras": 420.0, "multi_extras": float(EXTRAS_LIMIT_S), "cpu_baseline": 120.0, "finish": 90.0,
-              "in_process_timed": 300.0}
+              "in_process_timed": 300.0, "in_process_rccl": 240.0}
 
     def __init__(self, rank: int, device):
         self.rank, self.device = rank, device

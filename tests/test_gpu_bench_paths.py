@@ -121,6 +121,25 @@ def test_in_process_two_workers_one_gpu():
     assert [d["worker"] for d in line["config"]["rank_devices"]] == [0, 1] and len(r.stdout.encode()) <= 4096
 
 
+def test_in_process_rccl_leg_that_does_not_come_back_leaves_the_host_join_headline():
+    """The one-process path measures the host join FIRST (no communicator needed), then the in-library RCCL join under its own
+    phase limit: ncclCommInitAll over a broken fabric is a call nothing in the library can bound.  With that limit at 50 ms the
+    RCCL leg cannot finish: the watchdog prints the host-join headline it already has (extra.error says why) and the process
+    leaves with status 3 -- a number exists whatever RCCL does."""
+    r = _run(["--gpus", "1", "--in-process", "--batch", "32", "--steps", "5", "--blocks", "0", "--no-extra", "--no-cpu-baseline"],
+             {"CAF_BENCH_PHASE_LIMITS": "in_process_rccl=0.05"}, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    (line,) = _lines(r.stdout)
+    assert line["value"] > 0 and "host join" in line["config"]["peak_exchange"] and line["config"]["rccl_world"] is None
+    assert "RCCL join" in line["extra"]["error"] and "did not finish phase 'in_process_rccl'" in r.stderr
+    # and with the default limit the same command's headline is the RCCL join, with the host join beside it in the record
+    r = _run(["--gpus", "1", "--in-process", "--batch", "32", "--steps", "5", "--blocks", "0", "--no-extra", "--no-cpu-baseline"], {}, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    (line,) = _lines(r.stdout)
+    assert "in-library RCCL" in line["config"]["peak_exchange"] and line["config"]["rccl_world_size"] == 1
+    assert set(r.detail["extra"]["forms"]) == {"host_join", "rccl_join"} and r.detail["extra"]["forms"]["host_join"]["value"] > 0
+
+
 def test_a_failed_torchrun_tree_falls_back_to_the_one_process_path_on_the_gpu():
     """VERDICT r05 #3 on the GPU: the two-rank rehearsal with rank 1 asleep inside the timed loop ends non-zero without a line;
     the launcher then runs `--in-process` (two workers on this one GPU: --in-process-devices 0,0) as a second fresh child and
