@@ -399,7 +399,9 @@ int caf_multi_surface_run_batch(caf_multi_surface *h, const void *needles, const
 int caf_multi_surface_batch_results(caf_multi_surface *h, int worker, size_t *batch, void **d_slab, uint64_t **d_row_idx,
                                     void **d_row_val, caf_peak **d_peaks, const caf_peak **h_peaks);
 /* last run: seconds2 = {fan-out + shards + join of the worker threads, peak reduction}; shard_peaks[ndev] = every
- * worker's own find_peak record (global row positions); either may be NULL */
+ * worker's own find_peak record (global row positions); either may be NULL.  (A batch re-run of resident pairs with
+ * CAF_MULTI_REDUCE_RCCL and no row records wanted queues the RCCL join behind the row launches and waits ONCE: the
+ * devices' compute time then shows up in the second figure.) */
 int caf_multi_surface_run_stats(caf_multi_surface *h, double *seconds2, caf_peak *shard_peaks);
 /* HIP-event time of every worker's row kernel between begin and end: kernel_ms_total[ndev], launches[ndev] (n = 4096
  * plans run a surface as ONE launch and report no separate row-kernel time: launches 0) */
