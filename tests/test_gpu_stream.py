@@ -386,4 +386,13 @@ def test_stream_memcpy_nodes_form_equals_mapped_form(dtype, n, batch, nslots, en
         eng.synchronize()
         assert np.array_equal(i0.astype(np.int64), di.cpu().numpy()) and np.array_equal(v0, dv.cpu().numpy())
         assert p0.tobytes() == dp.cpu().numpy().tobytes()
+    if (dtype, n, batch) == ("c128", 4096, 1):
+        # the flag forces the {copy, spectrum, rows, find_peak, copy} chain: asking for a single-launch form as well is refused,
+        # not silently ignored; the older three-node chain and split chains go with it
+        from caf_cookoff_amd import _lib
+        for kw in (dict(one_kernel=True), dict(two_kernels=True)):
+            with pytest.raises(caf.CafError) as ei:
+                caf.Stream(plan, batch=1, nslots=2, memcpy_nodes=True, **kw)
+            assert ei.value.code == _lib.CAF_ERR_BAD_ARG and "CAF_STREAM_MEMCPY_NODES excludes" in str(ei.value)
+        caf.Stream(plan, batch=4, nslots=2, memcpy_nodes=True, split=True).close()
     plan.close()
