@@ -104,8 +104,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[2]/[3]/[4] measurements (N = 1)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the live FP64-VALU ceiling measurement")
-    ap.add_argument("--peak-reduce", choices=["allreduce", "allgather"], default="allreduce",
-                    help="N>1: RCCL all-reduce(max) + all-reduce(min key) (BASELINE north_star), or one all_gather")
+    ap.add_argument("--peak-reduce", choices=["fused", "allreduce", "allgather"], default="fused",
+                    help="N>1, the global-peak exchange per step: RCCL all-reduce(max) + all-reduce(min key) (BASELINE north_star) with the "
+                         "library's three element kernels either side (fused, caf_peak_exchange_stage: ~10 us of device time per step), "
+                         "the same two collectives with ~20 torch tensor operations around them (allreduce: what rounds 1-5 ran, and "
+                         "what `fused` falls back to on CPU tensors: gloo rehearsals, --plumbing-only), or one all_gather (allgather)")
     ap.add_argument("--overlap-peak-exchange", action="store_true",
                     help="N>1: run step k's peak exchange on a side stream under step k+1's kernels (alternating caf_peak "
                          "buffers): ~2 %% more surfaces/s with ONE rank under RCCL, but no multi-GPU box has run it yet, so the "
@@ -381,6 +384,11 @@ def in_process_main(args):
 
 
 # -------------------------------------------------------------------------- plumbing only --
+def torch_method(args):
+    """the torch-tensor form of the exchange for places without device records (gloo rehearsals, --plumbing-only, the extras)"""
+    return "allreduce" if args.peak_reduce == "fused" else args.peak_reduce
+
+
 def _test_stall(rank, phase, step):
     """CPU tests only: CAF_BENCH_TEST_STALL="rank=1,phase=timed,seconds=60" makes that rank sleep inside that phase's loop;
     "...,raise=1" makes it raise instead (a rank that fails alone while the others sit in the collective)."""
@@ -421,7 +429,7 @@ def plumbing_only(args):
         wd.enter("warmup")
         for i in range(max(1, args.warmup)):
             _test_stall(rank, "warmup", i)
-            gmax, grow, gidx = reduce_global_peak(val, row, idx, method=args.peak_reduce)
+            gmax, grow, gidx = reduce_global_peak(val, row, idx, method=torch_method(args))
         wd.enter("check")
         gate = torch.equal(grow, want_row) and torch.equal(gidx, torch.arange(nsurf) + 100) and bool((gmax == 9.0).all())
         if not gate or os.environ.get("CAF_BENCH_TEST_FAIL_GATE") == "1":   # (the variable: CPU tests of what a failed gate does)
@@ -433,7 +441,7 @@ def plumbing_only(args):
         t0 = time.perf_counter()
         for i in range(args.steps):
             _test_stall(rank, "timed", i)
-            gmax, grow, gidx = reduce_global_peak(val, row, idx, method=args.peak_reduce)
+            gmax, grow, gidx = reduce_global_peak(val, row, idx, method=torch_method(args))
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -452,7 +460,7 @@ def plumbing_only(args):
     v3 = torch.tensor([7.0 if own else 0.5], dtype=torch.float64)
     r3 = torch.tensor([2500 if own else lo3], dtype=torch.int64)
     i3 = torch.tensor([123 if own else 9], dtype=torch.int64)
-    g3 = reduce_global_peak(v3, r3, i3, method=args.peak_reduce)
+    g3 = reduce_global_peak(v3, r3, i3, method=torch_method(args))
     first, stride, items = caf.multi_stream_share(1000, world, rank)
     cnt = torch.tensor([items], dtype=torch.int64)
     tmax = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
@@ -481,7 +489,7 @@ def plumbing_only(args):
                             K=args.steps, el=el, kern_ms=None, launches=0,
                             kernel_name="caf::k_seq_rows<double, 15, caf::SeqIo<double> >", kernel_path="fused4096",
                             devname="none (plumbing only)", cu=0, ndev=0,
-                            peak_exchange=f"{args.peak_reduce}, on the main stream" if world > 1 else None,
+                            peak_exchange=f"{torch_method(args)}, on the main stream" if world > 1 else None,
                             rank_devices=[{"rank": int(t[0]), "device": int(t[1]), "visible": int(t[2])} for t in allrd],
                             rccl_world={"world_size": n_seen, "backend": backend} if world > 1 else None,
                             rank_kernel_ms=[float(t.item()) for t in allk])
@@ -526,7 +534,7 @@ def main():
     import torch.distributed as dist
 
     import caf_cookoff_amd as caf
-    from caf_cookoff_amd.dist import reduce_global_peak
+    from caf_cookoff_amd.dist import PeakExchange, reduce_global_peak
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists)")
@@ -588,13 +596,16 @@ def main():
         case = Case(eng, torch, dev, n_samp, freqs, args.dtype, nsurf, lo, hi)
         plan = case.plan
 
-        # find_peak across the row shards (dist.reduce_global_peak with --peak-reduce: RCCL all-reduce(max) + all-reduce(min
-        # key), the form BASELINE's north_star names, or one all_gather of 16 B per surface and rank + a local reduction).
-        # Default: on the main stream, behind the step's find_peak kernel (~0.1 ms of a 3.9 ms step during which the chip
-        # idles: 63.7 k vs 65.5 k surfaces/s with one rank).  --overlap-peak-exchange: on a side stream behind an event
+        # find_peak across the row shards (--peak-reduce): RCCL all-reduce(max) + all-reduce(min key), the form BASELINE's
+        # north_star names -- with the library's three element kernels either side (fused: dist.PeakExchange, round 6) or with
+        # ~20 torch tensor operations around them (allreduce: dist.reduce_global_peak, ~0.1 ms of a 3.9 ms step during which the
+        # chip idles: 63.7 k vs 65.5 k surfaces/s with one rank) -- or one all_gather of 16 B per surface and rank + a local
+        # reduction.  On the main stream, behind the step's find_peak kernel.  --overlap-peak-exchange: on a side stream behind an event
         # recorded after this step's find_peak kernel, on alternating caf_peak buffers; the main stream waits for a
         # buffer's previous exchange before the kernels write it again.
         overlap = coll and not rehearse and args.overlap_peak_exchange
+        method = torch_method(args) if (rehearse or overlap) else args.peak_reduce   # (gloo moves CPU tensors; the side stream is torch's)
+        px = PeakExchange(eng, nsurf, freqs, dev) if (coll and method == "fused") else None
         peaks = [case.peak, torch.empty_like(case.peak)] if coll else [case.peak]
         side = torch.cuda.Stream(device=dev) if overlap else None
         ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
@@ -613,11 +624,14 @@ def main():
                 case.launch(peak=pk)
                 pk_c = pk.cpu()
                 pk_ci = pk_c.view(torch.int64)
-                return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2], method=args.peak_reduce, always_collective=True)
+                return reduce_global_peak(pk_c[:, 0], pk_ci[:, 3], pk_ci[:, 2], method=method, always_collective=True)
+            if px is not None:
+                case.launch(peak=pk)
+                return PeakExchange.peaks_of(px(pk, always_collective=True))   # (views of the exchange's output records: no kernel)
             if not overlap:
                 case.launch(peak=pk)
                 pki = pk.view(torch.int64)
-                return reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=args.peak_reduce, always_collective=True)
+                return reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=method, always_collective=True)
             main_stream = torch.cuda.current_stream()
             if used[k]:
                 main_stream.wait_event(ev_done[k])
@@ -626,7 +640,7 @@ def main():
             with torch.cuda.stream(side):
                 side.wait_event(ev_ready[k])
                 pki = pk.view(torch.int64)
-                out = reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=args.peak_reduce, always_collective=True)
+                out = reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=method, always_collective=True)
                 ev_done[k].record(side)
             used[k] = True
             return out
@@ -706,7 +720,7 @@ def main():
         res = assemble_line(args, F=F, n_samp=n_samp, world=world, n_gpus_seen=n_gpus_seen, nsurf=nsurf, rows=rows, K=K, el=el,
                             kern_ms=kern_ms, launches=launches, kernel_name=plan.kernel_name, kernel_path=plan.path,
                             devname=devname, cu=cu, ndev=ndev,
-                            peak_exchange=(f"{args.peak_reduce}, {'overlapped on a side stream' if overlap else 'on the main stream'}"
+                            peak_exchange=(f"{method}, {'overlapped on a side stream' if overlap else 'on the main stream'}"
                                            if coll else None), rank_devices=rank_devices,
                             rccl_world={"world_size": dist.get_world_size(), "backend": dist.get_backend()} if coll else None,
                             rank_kernel_ms=rank_kernel_ms)

@@ -397,6 +397,7 @@ def multi_gpu_extras(args, eng, torch, dist, dev, rank, world, rehearse, freqs):
     from caf_cookoff_amd.dist import reduce_global_peak
     from caf_cookoff_amd.synth import make_batch
     cdev = "cpu" if rehearse else dev
+    method = "allreduce" if args.peak_reduce == "fused" else args.peak_reduce   # (one surface per step here: the tensor form is enough)
 
     def all_max(x):
         t = torch.tensor([x], dtype=torch.float64, device=cdev)
@@ -423,7 +424,7 @@ def multi_gpu_extras(args, eng, torch, dist, dev, rank, world, rehearse, freqs):
         c.launch()
         pk = c.peak.cpu() if rehearse else c.peak
         pki = pk.view(torch.int64)
-        return reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=args.peak_reduce, always_collective=True)
+        return reduce_global_peak(pk[:, 0], pki[:, 3], pki[:, 2], method=method, always_collective=True)
 
     for _ in range(2):
         g = step3()
@@ -442,7 +443,7 @@ def multi_gpu_extras(args, eng, torch, dist, dev, rank, world, rehearse, freqs):
     ab = algorithmic_bytes(1, hi - lo, 32768, "c64")
     out["configs3_c64_sharded"] = {
         "workload": f"ONE 4096x65536 complex64 surface, Doppler rows sharded over {world} ranks "
-                    f"({hi - lo} rows on rank 0) + RCCL peak reduction ({args.peak_reduce}) (BASELINE configs[3])",
+                    f"({hi - lo} rows on rank 0) + RCCL peak reduction ({method}) (BASELINE configs[3])",
         "value": K3 / el, "unit": "surfaces/s", "ms_per_surface": el / K3 * 1e3, "steps": K3,
         "rank0_kernel_ms": kms / max(1, nl), "rank0_kernel": c.plan.kernel_name, "global_peak_correct": bool(ok3),
         "rank0_algorithmic_bytes": ab, "rank0_frac": roofline_entry(ab, kms / max(1, nl))["frac"]}

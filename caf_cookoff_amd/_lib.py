@@ -129,6 +129,7 @@ SYMBOLS = [
     ("caf_multi_surface_host_register", _int, [_vp, _vp, _sz]),
     ("caf_multi_surface_host_unregister", _int, [_vp, _vp]),
     ("caf_multi_surface_destroy", _int, [_vp]),
+    ("caf_peak_exchange_stage", _int, [_vp, _int, _vp, _sz, _vp, _vp, _sz, _vp]),
     ("caf_debug_guard_bands", _int, [_sz]),
     ("caf_debug_check_guards", _int, [ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
 ]

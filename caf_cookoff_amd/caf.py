@@ -232,6 +232,14 @@ class Engine:
         self._check(self.lib.caf_find_peak(self._h, _dptr(fr), _uptr(ri), _dptr(rv), F, ctypes.byref(peak)))
         return float(peak.freq), int(peak.idx)
 
+    def peak_exchange_stage(self, stage: int, d_peaks: int, count: int, d_red: int, d_freqs_all: int = 0, nfreq_all: int = 0,
+                            d_out: int = 0):
+        """``caf_peak_exchange_stage``: one of the three element-sized kernels around the two collectives of the global-peak
+        exchange of row shards (device pointers; asynchronous on the engine's stream): see :class:`caf_cookoff_amd.dist.PeakExchange`."""
+        self._check(self.lib.caf_peak_exchange_stage(self._h, int(stage), ctypes.c_void_p(d_peaks or None), int(count),
+                                                     ctypes.c_void_p(d_red), ctypes.c_void_p(d_freqs_all or None), int(nfreq_all),
+                                                     ctypes.c_void_p(d_out or None)))
+
     # -- views in the Go / Python implementations' conventions (SURVEY.md 8f.3) -----
     def surface_view(self, surface: np.ndarray, view: str) -> np.ndarray:
         """``view='go'``: caf_go amb_surf (2n lags, |.|, lag = n - k, caf.go:95-116, main.go:35);

@@ -32,4 +32,44 @@ __global__ void k_shard_peak_key(const caf_peak *__restrict__ peak, double *__re
     }
 }
 
+// ---- the same exchange for hosts that run the collectives THEMSELVES (one process per GPU: torch.distributed over RCCL, MPI ...):
+// caf_peak_exchange_stage (api/ops.inc).  In-place collectives and SIGNED 64-bit keys (torch and MPI reduce int64, not uint64):
+// a row position is < 2^31, so a key is a positive int64 and INT64_MAX means "this shard does not hold the maximum".
+//   stage 0   val[b] = gmax[b] = this shard's peak value (0.0 without a peak)      -> the host all-reduces gmax with MAX, in place
+//   stage 1   key[b] = gkey[b] = (row << 32 | idx) if the shard holds gmax[b] > 0  -> the host all-reduces gkey with MIN, in place
+//   stage 2   out[b] = {gmax, freqs_all[row], idx, row}, or the reference's initial maximum {0, 0, 0, -1} (mod.rs:32-35)
+__global__ void k_px_val(const caf_peak *__restrict__ peak, double *__restrict__ red, int count)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < count) red[b] = red[count + b] = peak[b].row >= 0 ? peak[b].val : 0.0;
+}
+__global__ void k_px_key(const caf_peak *__restrict__ peak, double *__restrict__ red, int count)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < count) {
+        const double gmax = red[count + b];
+        const bool mine = peak[b].row >= 0 && gmax > 0.0 && peak[b].val == gmax;
+        const int64_t key = mine ? (int64_t)(((uint64_t)peak[b].row << 32) | (peak[b].idx & 0xffffffffull)) : INT64_MAX;
+        ((int64_t *)red)[2 * (size_t)count + b] = ((int64_t *)red)[3 * (size_t)count + b] = key;
+    }
+}
+__global__ void k_px_out(const double *__restrict__ red, const double *__restrict__ freqs_all, long nfreq_all,
+                         caf_peak *__restrict__ out, int count)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < count) {
+        const int64_t key = ((const int64_t *)red)[3 * (size_t)count + b];
+        caf_peak pk;
+        if (key == INT64_MAX) {
+            pk.val = 0.0; pk.freq = 0.0; pk.idx = 0; pk.row = -1;
+        } else {
+            pk.val = red[count + b];
+            pk.row = key >> 32;
+            pk.idx = (uint64_t)key & 0xffffffffull;
+            pk.freq = pk.row < nfreq_all ? freqs_all[pk.row] : 0.0;
+        }
+        out[b] = pk;
+    }
+}
+
 }  // namespace caf

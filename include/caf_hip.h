@@ -415,6 +415,20 @@ int caf_multi_surface_host_register(caf_multi_surface *h, void *ptr, size_t byte
 int caf_multi_surface_host_unregister(caf_multi_surface *h, void *ptr);
 int caf_multi_surface_destroy(caf_multi_surface *h);
 
+/* ---- the peak exchange for hosts that run the collectives themselves (one process per GPU) -------------
+ * find_peak over contiguous row shards (mod.rs:31-42 over the joined rows: largest value, among equal values the lowest
+ * global row) = all-reduce(MAX) over the shards' peak values + all-reduce(MIN) over (global_row << 32 | idx) keys of the
+ * shards that hold the maximum (RCCL has no MAXLOC).  caf_multi_surface_* runs both inside the library; a host with one
+ * process per GPU (torch.distributed, MPI) runs the two collectives itself and takes the three element-sized kernels around
+ * them from here.  d_peaks: the `count` shard records caf_surface_dev left on this context's device (global row positions);
+ * d_red: 4 * count 8-byte words of device memory, laid out [val | gmax | key | gkey]; asynchronous, on the context's stream.
+ *   stage 0   gmax[b] = this shard's peak value (0.0 without a peak)            then all-reduce gmax[0..count) with MAX, IN PLACE (f64)
+ *   stage 1   gkey[b] = (row << 32 | idx) if this shard holds gmax[b] > 0, else INT64_MAX   then all-reduce gkey with MIN, IN PLACE (int64)
+ *   stage 2   d_out[b] = {gmax, freqs_all[row], idx, row}; {0.0, 0.0, 0, -1} if no shard had a peak (the reference's initial maximum)
+ * Keys are SIGNED 64-bit (a row position is < 2^31): torch and MPI reduce int64. */
+int caf_peak_exchange_stage(caf_ctx *ctx, int stage, const caf_peak *d_peaks, size_t count, void *d_red,
+                            const double *d_freqs_all, size_t nfreq_all, caf_peak *d_out);
+
 /* ---- debug: red zones ---------------------------------------------------------------------------------------------
  * GPU AddressSanitizer is not available for this target, so the library can police its own allocations: after
  * caf_debug_guard_bands(bytes) every device / pinned allocation the library makes (tables, spectra, slabs, staging, stream

@@ -41,12 +41,85 @@ for method in ("allgather", "allreduce"):
     torch.cuda.synchronize()
     assert g.tolist() == [3.5, 0.0, 7.25, 7.25], (method, g)
     assert r.tolist() == [12, -1, 399, 0] and i.tolist() == [202, 0, 8191, 70], (method, r, i)
+# the same exchange with the library's element kernels either side of the two collectives (dist.PeakExchange): same answer
+import numpy as np
+import caf_cookoff_amd as caf
+from caf_cookoff_amd.dist import PeakExchange
+eng = caf.Engine(0)
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+freqs = np.arange(400) * 0.5 - 100.0
+rec = torch.zeros((4, 4), dtype=torch.float64, device="cuda")
+rec[:, 0] = val
+reci = rec.view(torch.int64)
+reci[:, 2], reci[:, 3] = idx, row
+px = PeakExchange(eng, 4, freqs, torch.device("cuda", 0))
+out = px(rec, always_collective=True)
+g, r, i = PeakExchange.peaks_of(out)
+torch.cuda.synchronize()
+assert g.tolist() == [3.5, 0.0, 7.25, 7.25] and r.tolist() == [12, -1, 399, 0] and i.tolist() == [202, 0, 8191, 70], (g, r, i)
+assert out[:, 1].tolist() == [freqs[12], 0.0, freqs[399], freqs[0]]
+eng.close()
 dist.barrier()
 dist.destroy_process_group()
 print("rccl ok")
 """ % str(root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_peak_exchange_stages_equal_the_host_rule(eng):
+    """caf_peak_exchange_stage (the three element kernels a one-process-per-GPU host puts around ITS OWN two collectives) against
+    the host rule of the same join (caf_multi_surface_reduce): 3 shards x 500 surfaces of random shard records with ties across
+    shards (values from a small set), shards without a peak and surfaces where no shard has one; the two all-reduces are played
+    by torch.maximum / torch.minimum over the shards' buffers, as MAX over f64 and MIN over int64 would."""
+    import torch
+    import caf_cookoff_amd as caf
+    rng = np.random.default_rng(77)
+    G, count, F = 3, 500, 400
+    freqs = np.arange(F) * 0.5 - 100.0
+    shards = np.zeros((G, count), dtype=caf.Stream.PEAK_DTYPE)
+    for g in range(G):
+        lo, hi = caf.multi_surface_shard(F, G, g)
+        has = rng.random(count) < 0.8
+        shards[g]["row"] = np.where(has, rng.integers(lo, hi, count), -1)
+        shards[g]["val"] = np.where(has, rng.choice([1.0, 2.5, 2.5, 7.0, 0.0], count), 0.0)
+        shards[g]["idx"] = np.where(has, rng.integers(0, 8192, count), 0)
+        shards[g]["freq"] = np.where(has, freqs[np.maximum(shards[g]["row"], 0)], 0.0)
+    shards[:, :7]["row"] = -1                                   # seven surfaces without any peak
+    want = np.array([caf.multi_surface_reduce(shards[:, b]) for b in range(count)], dtype=caf.Stream.PEAK_DTYPE)
+    dev_recs = [torch.from_numpy(shards[g].view(np.float64).reshape(count, 4).copy()).cuda() for g in range(G)]
+    reds = [torch.empty(4 * count, dtype=torch.float64, device="cuda") for _ in range(G)]
+    d_freqs = torch.from_numpy(freqs).cuda()
+    out = torch.empty((count, 4), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for g in range(G):
+        eng.peak_exchange_stage(0, dev_recs[g].data_ptr(), count, reds[g].data_ptr())
+    eng.synchronize()
+    gmax = torch.stack([r[count:2 * count] for r in reds]).max(dim=0).values          # all-reduce(MAX) over f64
+    for r in reds:
+        r[count:2 * count] = gmax
+    torch.cuda.synchronize()
+    for g in range(G):
+        eng.peak_exchange_stage(1, dev_recs[g].data_ptr(), count, reds[g].data_ptr())
+    eng.synchronize()
+    gkey = torch.stack([r.view(torch.int64)[3 * count:] for r in reds]).min(dim=0).values   # all-reduce(MIN) over int64
+    for r in reds:
+        r.view(torch.int64)[3 * count:] = gkey
+    torch.cuda.synchronize()
+    eng.peak_exchange_stage(2, 0, count, reds[1].data_ptr(), d_freqs.data_ptr(), F, out.data_ptr())
+    eng.synchronize()
+    got = out.cpu().numpy().view(caf.Stream.PEAK_DTYPE)[:, 0]
+    assert got.tobytes() == want.tobytes()
+    assert int((want["row"] == -1).sum()) >= 7 and len(np.unique(want["val"])) >= 3
+    # argument checks
+    from caf_cookoff_amd import _lib
+    for bad in (lambda: eng.peak_exchange_stage(3, dev_recs[0].data_ptr(), count, reds[0].data_ptr()),
+                lambda: eng.peak_exchange_stage(0, 0, count, reds[0].data_ptr()),
+                lambda: eng.peak_exchange_stage(2, 0, count, reds[0].data_ptr(), d_freqs.data_ptr(), F, 0),
+                lambda: eng.peak_exchange_stage(0, dev_recs[0].data_ptr(), count, reds[0].data_ptr() + 4)):
+        with pytest.raises(caf.CafError) as ei:
+            bad()
+        assert ei.value.code == _lib.CAF_ERR_BAD_ARG
 
 
 # ------------------------------------------------------ surface-parallel multi-device driver --
