@@ -638,10 +638,18 @@ def n1_extras(args, eng, torch, dev, local_rank, freqs, K, extra):
     leg("in_process_headline")
     try:
         # the headline itself through the C ABI's batched row-shard call (what `bench.py --in-process` times), RCCL join with one
-        # rank (--sweeps: the host join and the call with the upload inside beside it)
-        extra["in_process_headline"] = in_process_headline([local_rank], args.batch, steps=max(5, min(K, 30)), warmup=5,
-                                                           forms=("rccl_join", "host_join") if args.sweeps else ("rccl_join",),
-                                                           check=not args.no_check, timeout_s=60.0, with_upload=args.sweeps)
+        # rank (--sweeps: the host join and the call with the upload inside beside it); if RCCL cannot be used on this box (not
+        # loadable, no communicator, the join runs into the deadline) the host join is measured instead and the record says why
+        import caf_cookoff_amd as caf_
+        kw = dict(steps=max(5, min(K, 30)), warmup=5, check=not args.no_check, timeout_s=60.0, with_upload=args.sweeps)
+        try:
+            extra["in_process_headline"] = in_process_headline([local_rank], args.batch, forms=("rccl_join", "host_join") if args.sweeps
+                                                               else ("rccl_join",), **kw)
+        except caf_.CafError as e:
+            if e.code not in (caf_._lib.CAF_ERR_RCCL, caf_._lib.CAF_ERR_TIMEOUT):
+                raise
+            extra["in_process_headline"] = in_process_headline([local_rank], args.batch, forms=("host_join",), **kw)
+            extra["in_process_headline"]["rccl_join"] = {"error": str(e)}
     except Exception as e:
         extra["in_process_headline"] = {"error": f"{type(e).__name__}: {e}"}
     leg(None)

@@ -70,8 +70,12 @@ def test_the_drivers_exact_command_yields_one_small_parseable_line():
     # the full record: same headline, only the two streaming forms of a default run, no sweep legs
     det = r.detail
     assert det["value"] == line["value"] and set(det["extra"]["configs4_stream"]["forms"]) == {"batched20_2slots", "batched20_2slots_memcpy_nodes"}
-    assert "in_process_multi" not in det["extra"] and set(det["extra"]["in_process_headline"]) == {"rccl_join"}
-    assert det["extra"]["in_process_headline"]["rccl_join"]["with_upload"] is None
+    iph = det["extra"]["in_process_headline"]
+    assert "in_process_multi" not in det["extra"] and "rccl_join" in iph
+    if "value" in iph["rccl_join"]:                        # (RCCL usable on this box: the only form a default run measures)
+        assert set(iph) == {"rccl_join"} and iph["rccl_join"]["with_upload"] is None and ex["in_process_headline"]["join"] == "rccl"
+    else:                                                  # (not usable: the host join was measured instead and the record says why)
+        assert iph["host_join"]["value"] > 0 and iph["rccl_join"]["error"] and ex["in_process_headline"]["join"] == "host"
     ps = ex["phase_seconds"]
     print("phase_seconds", ps, "wall", round(wall, 1), "legs", det["extra"].get("extras_leg_seconds"))
     # target <= 6 s: 2.9-3.2 s on the round-6 builder boxes (profiles/r06_misc), 9.2 s when the C++ child still loaded the
