@@ -187,11 +187,14 @@ class RankFallback:
             return 3
         if self.rank == 0:
             time.sleep(float(os.environ.get("CAF_BENCH_FALLBACK_SETTLE_S", "3")))   # let the other ranks reach their own limits
-            ok = run_in_process_fallback(self.args, {"path": "torchrun (external launcher)", "rc": None, "stderr_tail": reason})
+            ok = False
             try:
-                self.flag.write_text("ok" if ok else "fail")
-            except OSError:
-                pass
+                ok = run_in_process_fallback(self.args, {"path": "torchrun (external launcher)", "rc": None, "stderr_tail": reason})
+            finally:   # (whatever happened here, the other ranks must not wait out their whole patience for a verdict)
+                try:
+                    self.flag.write_text("ok" if ok else "fail")
+                except OSError:
+                    pass
             return 0 if ok else 3
         t_end = time.monotonic() + self.WAIT_S
         os.write(2, f"bench.py: rank {self.rank}: {reason}; waiting for rank 0's one-process fallback\n".encode())
