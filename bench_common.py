@@ -408,7 +408,8 @@ class PhaseWatchdog:
 
     # (a healthy default run spends < 1 s in each of the first five, ~8 s in the blocks, ~10 s in the N = 1 extras; the limits
     #  are sized so that a rank stuck in any ONE phase leaves well inside a 600-second outer limit)
-    LIMITS = {"rendezvous": 150.0, "setup": 180.0, "warmup": 120.0, "check": 90.0, "timed": 150.0, "blocks": 180.0,
+    # (rendezvous: 240 s -- on a fresh node the ranks' first `import torch` can take minutes and they do not finish it together)
+    LIMITS = {"rendezvous": 240.0, "setup": 180.0, "warmup": 120.0, "check": 90.0, "timed": 150.0, "blocks": 180.0,
               "ceiling": 120.0, "extras": 420.0, "multi_extras": float(EXTRAS_LIMIT_S), "cpu_baseline": 120.0, "finish": 90.0,
               "in_process_timed": 300.0, "in_process_rccl": 240.0}
 
